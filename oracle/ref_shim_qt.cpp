@@ -1,0 +1,80 @@
+// TEST INFRASTRUCTURE ONLY.  C-ABI wrapper around the reference's real DownChannelizer
+// (QObject; sdrbase/dsp/downchannelizer.{h,cpp}) so that the float bisection
+// (createFilterChain, downchannelizer.cpp:250-287) and feed() (:50-91) can be run as they are.
+// Needs Qt5Core + moc, both present in this image under /opt/conda; built by `make ref_qt`
+// into oracle/_ref/libsdrref_qt.so.  Never shipped, never loaded by the product.
+#include <stdint.h>
+#include <vector>
+#include "dsp/downchannelizer.h"
+#include "dsp/dspcommands.h"
+#include "util/messagequeue.h"
+
+namespace {
+
+class CollectSink : public BasebandSampleSink {
+public:
+    std::vector<Sample> got;
+    void start() override {}
+    void stop() override {}
+    void feed(const SampleVector::const_iterator& b, const SampleVector::const_iterator& e, bool) override
+    { got.insert(got.end(), b, e); }
+    bool handleMessage(const Message&) override { return false; }
+};
+
+class OpenChannelizer : public DownChannelizer {
+public:
+    explicit OpenChannelizer(BasebandSampleSink* s) : DownChannelizer(s) {}
+    int nStages() const { return (int) m_filterStages.size(); }
+    void modes(uint8_t* out) const
+    {
+        int i = 0;
+        for (FilterStages::const_iterator it = m_filterStages.begin(); it != m_filterStages.end(); ++it)
+            out[i++] = (uint8_t) (*it)->m_mode;     // ModeCenter=0, ModeLowerHalf=1, ModeUpperHalf=2
+    }
+    int outRate() const { return m_currentOutputSampleRate; }
+    int ofs() const { return m_currentCenterFrequency; }
+};
+
+struct Holder {
+    CollectSink sink;
+    OpenChannelizer chan;
+    Holder() : chan(&sink) {}
+};
+
+void drain(MessageQueue* q) { Message* m; while ((m = q->pop()) != 0) delete m; }
+
+} // namespace
+
+extern "C" {
+
+void* refqt_chan_new(int in_rate, int req_rate, int req_fc)
+{
+    Holder* h = new Holder;
+    DSPSignalNotification sig(in_rate, 0);
+    h->chan.handleMessage(sig);                       // sets m_inputSampleRate, applyConfiguration
+    DSPConfigureChannelizer cfg(req_rate, req_fc);
+    h->chan.handleMessage(cfg);                       // the message DownChannelizer::configure posts
+    drain(h->sink.getInputMessageQueue());
+    return h;
+}
+void refqt_chan_free(void* p) { Holder* h = static_cast<Holder*>(p); drain(h->sink.getInputMessageQueue()); delete h; }
+
+int refqt_chan_plan(void* p, uint8_t* modes, int* out_rate, int* ofs)
+{
+    Holder* h = static_cast<Holder*>(p);
+    h->chan.modes(modes); *out_rate = h->chan.outRate(); *ofs = h->chan.ofs();
+    return h->chan.nStages();
+}
+
+int64_t refqt_chan_feed(void* p, const int16_t* iq, int64_t n_cplx, int16_t* out)
+{
+    Holder* h = static_cast<Holder*>(p);
+    SampleVector v((size_t) n_cplx);
+    for (int64_t i = 0; i < n_cplx; i++) v[i] = Sample(iq[2*i], iq[2*i+1]);
+    h->sink.got.clear();
+    h->chan.feed(v.begin(), v.end(), false);
+    for (size_t i = 0; i < h->sink.got.size(); i++) { out[2*i] = h->sink.got[i].real(); out[2*i+1] = h->sink.got[i].imag(); }
+    return (int64_t) h->sink.got.size();
+}
+
+} // extern "C"

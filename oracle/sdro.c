@@ -1,0 +1,255 @@
+/* TEST INFRASTRUCTURE -- see sdro.h.  Integer half-band path of the oracle.
+ *
+ * Restated from the *behaviour* of the reference (closed forms of SURVEY.md Appendix A), not
+ * from its ring-buffer code: each stage keeps a plain 64-deep delay line of its (rotated)
+ * inputs and evaluates
+ *
+ *     M = index of the newest (odd) input,  N = order, P = N/4, S = hbShift = 12
+ *     acc = sum_{i<P} c[i] * ( x[M-2i] + x[M-(N-2)+2i] )  +  ( x[M-(N/2-1)] << (S-1) )
+ *     y   = acc >> (S-1)          (int32 wrap-around arithmetic, arithmetic shift)
+ *
+ * which is what IntHalfbandFilterEO::storeSample32/advancePointer/doFIR
+ * (inthalfbandfiltereo.h:769-790, 832-870) produce for every second input.
+ */
+#include "sdro.h"
+#include <stdlib.h>
+#include <string.h>
+
+/* hbfiltertraits.cpp:136-154 / :85-99 -- (int32)(c * 4096), truncation toward zero */
+static const int32_t HB64[16] = { -1, 2, -5, 8, -12, 17, -25, 35, -47, 64, -86, 117, -164, 244, -424, 1300 };
+static const int32_t HB48[12] = { -4, 7, -12, 19, -31, 48, -71, 103, -152, 236, -419, 1299 };
+#define HB_SHIFT 12
+
+typedef struct {
+    int order;            /* 64 (Decimators) or 48 (DownChannelizer) */
+    const int32_t* c;
+    int mode;             /* 0 centre, 1 lower/inf (x j^(n+1)), 2 upper/sup (x (-j)^(n+1)) */
+    int narrow;           /* 1: Sample (int16) flavour -- int16 negation and int16 store */
+    uint32_t n;           /* inputs seen since construction (rotation phase = n & 3, parity = n & 1) */
+    int32_t re[64], im[64];
+} hb_stage;
+
+static void hb_init(hb_stage* s, int order, int mode, int narrow)
+{
+    memset(s, 0, sizeof *s);
+    s->order = order;
+    s->c = order == 64 ? HB64 : HB48;
+    s->mode = mode;
+    s->narrow = narrow;
+}
+
+static inline int32_t neg(const hb_stage* s, int32_t v)
+{
+    /* (FixReal) -sample->imag()  (inthalfbandfiltereo.h:164): negate in int, cast to int16 */
+    return s->narrow ? (int32_t)(int16_t)(uint16_t)(0u - (uint32_t)v) : (int32_t)(0u - (uint32_t)v);
+}
+
+/* push one input; returns 1 and overwrites *re,*im when an output is produced */
+static inline int hb_push(hb_stage* s, int32_t* re, int32_t* im)
+{
+    int32_t xr = *re, xi = *im;
+    const uint32_t ph = s->n & 3u;
+    if (s->mode == 1) {          /* j^(n+1): (-y,x) (-x,-y) (y,-x) (x,y)   (:626-658, 158-206) */
+        switch (ph) {
+        case 0: { int32_t t = xr; xr = neg(s, xi); xi = t; break; }
+        case 1: xr = neg(s, xr); xi = neg(s, xi); break;
+        case 2: { int32_t t = xr; xr = xi; xi = neg(s, t); break; }
+        default: break;
+        }
+    } else if (s->mode == 2) {   /* (-j)^(n+1): (y,-x) (-x,-y) (-y,x) (x,y)  (:660-692, 357-405) */
+        switch (ph) {
+        case 0: { int32_t t = xr; xr = xi; xi = neg(s, t); break; }
+        case 1: xr = neg(s, xr); xi = neg(s, xi); break;
+        case 2: { int32_t t = xr; xr = neg(s, xi); xi = t; break; }
+        default: break;
+        }
+    }
+    const uint32_t M = s->n & 63u;
+    s->re[M] = xr; s->im[M] = xi;
+    const int odd = (int)(s->n & 1u);
+    s->n++;
+    if (!odd) return 0;
+
+    const int N = s->order, P = N / 4;
+    uint32_t ar = 0, ai = 0;
+    for (int i = 0; i < P; i++) {
+        const uint32_t a = (M - 2u * (uint32_t)i) & 63u;
+        const uint32_t b = (M - (uint32_t)(N - 2) + 2u * (uint32_t)i) & 63u;
+        ar += ((uint32_t)s->re[a] + (uint32_t)s->re[b]) * (uint32_t)s->c[i];
+        ai += ((uint32_t)s->im[a] + (uint32_t)s->im[b]) * (uint32_t)s->c[i];
+    }
+    const uint32_t m = (M - (uint32_t)(N / 2 - 1)) & 63u;
+    ar += (uint32_t)s->re[m] << (HB_SHIFT - 1);
+    ai += (uint32_t)s->im[m] << (HB_SHIFT - 1);
+    int32_t yr = (int32_t)ar >> (HB_SHIFT - 1);
+    int32_t yi = (int32_t)ai >> (HB_SHIFT - 1);
+    if (s->narrow) { yr = (int16_t)yr; yi = (int16_t)yi; }   /* Sample::setReal(FixReal) (:828-829) */
+    *re = yr; *im = yi;
+    return 1;
+}
+
+/* ------------------------------------------------------------------ Decimators */
+struct sdro_decim {
+    int log2, fcpos, bits;
+    int pre, post, group;
+    hb_stage st[6];
+};
+
+/* decimation_shifts<16,InputBits> (decimators.h:25-185) */
+static void shifts(int bits, int log2, int* pre, int* post)
+{
+    static const int pre12[7]  = { 4, 3, 2, 1, 0, 0, 0 }, post12[7] = { 0, 0, 0, 0, 0, 1, 2 };
+    static const int pre8[7]   = { 8, 7, 6, 5, 4, 3, 2 };
+    if (bits == 12) { *pre = pre12[log2]; *post = post12[log2]; }
+    else if (bits == 8) { *pre = pre8[log2]; *post = 0; }
+    else { *pre = 0; *post = log2; }                       /* <16,16> */
+}
+
+int32_t sdro_decim_group_int16(int log2, int fcpos)
+{
+    /* the `pos +=` strides of decimateK_{inf,sup,cen} (decimators.h:348 ... 3492) */
+    if (log2 == 0) return 2;
+    if (log2 <= 2) return 4 << log2;                        /* 8, 16 for every mode */
+    return fcpos == SDRO_FC_CEN ? (2 << log2) : (4 << log2);
+}
+
+void sdro_decim_reset(sdro_decim* d)
+{
+    const int L = d->log2;
+    for (int s = 0; s < L; s++) {
+        int mode = 0;
+        if (d->fcpos != SDRO_FC_CEN) {
+            /* inf: Inf,Sup,...,Sup,Cen ; sup: Sup,Inf,...,Inf,Cen ; L=1: single ; L=2: pair
+             * (call pattern of decimators.h:463-2584) */
+            const int first = d->fcpos == SDRO_FC_INF ? 1 : 2, other = 3 - first;
+            if (s == 0) mode = first;
+            else if (L >= 3 && s == L - 1) mode = 0;
+            else mode = other;
+        }
+        hb_init(&d->st[s], 64, mode, 0);
+    }
+}
+
+sdro_decim* sdro_decim_new(int log2, int fcpos, int bits)
+{
+    if (log2 < 0 || log2 > 6 || fcpos < 0 || fcpos > 2 || (bits != 8 && bits != 12 && bits != 16)) return 0;
+    sdro_decim* d = (sdro_decim*)calloc(1, sizeof *d);
+    d->log2 = log2; d->fcpos = fcpos; d->bits = bits;
+    shifts(bits, log2, &d->pre, &d->post);
+    d->group = sdro_decim_group_int16(log2, fcpos);
+    sdro_decim_reset(d);
+    return d;
+}
+
+void sdro_decim_free(sdro_decim* d) { free(d); }
+
+int32_t sdro_decim_process(sdro_decim* d, const int16_t* iq, int32_t n_int16, int16_t* out)
+{
+    if (n_int16 < d->group) return 0;
+    const int32_t n_cplx = (n_int16 / d->group) * (d->group / 2);
+    int32_t n_out = 0;
+    for (int32_t i = 0; i < n_cplx; i++) {
+        int32_t re = (int32_t)((uint32_t)(int32_t)iq[2*i]   << d->pre);
+        int32_t im = (int32_t)((uint32_t)(int32_t)iq[2*i+1] << d->pre);
+        int s = 0;
+        for (; s < d->log2; s++)
+            if (!hb_push(&d->st[s], &re, &im)) break;
+        if (s == d->log2) {
+            out[2*n_out]   = (int16_t)(re >> d->post);
+            out[2*n_out+1] = (int16_t)(im >> d->post);
+            n_out++;
+        }
+    }
+    return n_out;
+}
+
+/* ------------------------------------------------------------------ DownChannelizer */
+static int contains(float ss, float se, float cs, float ce)
+{
+    /* signalContainsChannel (downchannelizer.cpp:240-248) */
+    if (se <= ss) return 0;
+    if (ce <= cs) return 0;
+    return ss <= cs && se >= ce;
+}
+
+int32_t sdro_chan_plan(int32_t in_rate, int32_t req_rate, int32_t req_fc,
+                       uint8_t* modes, int32_t* out_rate, int32_t* residual_ofs)
+{
+    /* applyConfiguration (downchannelizer.cpp:157-189): ints first, then int -> float (Real) */
+    if (in_rate == 0) { *out_rate = 0; *residual_ofs = 0; return 0; }
+    float s = (float)(in_rate / -2), e = (float)(in_rate / 2);
+    float cs = (float)(req_fc - req_rate / 2), ce = (float)(req_fc + req_rate / 2);
+    int n = 0;
+    for (;;) {
+        /* createFilterChain (:250-287).  `x / 2.0` promotes to double, `x / 2.0f` stays float;
+         * every argument is rounded to float when passed (Real parameters). */
+        const float bw = e - s;
+        const float rot = bw / 4;
+        const float lo_end = (float)((double)s + (double)bw / 2.0 - 0.0);   /* safetyMargin = 0 */
+        const float up_start = e - bw / 2.0f + 0.0f;
+        if (n < 32 && contains(s + 0.0f, lo_end, cs, ce)) {
+            modes[n++] = SDRO_MODE_LOWER;
+            e = (float)((double)s + (double)bw / 2.0);
+            continue;
+        }
+        if (n < 32 && contains(up_start, e - 0.0f, cs, ce)) {
+            modes[n++] = SDRO_MODE_UPPER;
+            s = e - bw / 2.0f;
+            continue;
+        }
+        if (n < 32 && contains(s + rot + 0.0f, e - rot - 0.0f, cs, ce)) {
+            modes[n++] = SDRO_MODE_CENTER;
+            const float ns = s + rot, ne = e - rot;
+            s = ns; e = ne;
+            continue;
+        }
+        const float ofs = (float)((((double)(ce - cs)) / 2.0 + (double)cs) - (((double)(e - s)) / 2.0 + (double)s));
+        *residual_ofs = (int32_t)ofs;                      /* Real -> int m_currentCenterFrequency */
+        break;
+    }
+    *out_rate = in_rate / (1 << n);
+    return n;
+}
+
+struct sdro_chain {
+    int n;
+    uint8_t modes[32];
+    hb_stage st[32];
+};
+
+void sdro_chain_reset(sdro_chain* c)
+{
+    for (int i = 0; i < c->n; i++) hb_init(&c->st[i], 48, c->modes[i], 1);
+}
+
+sdro_chain* sdro_chain_new(int32_t n_stages, const uint8_t* modes)
+{
+    if (n_stages < 0 || n_stages > 32) return 0;
+    sdro_chain* c = (sdro_chain*)calloc(1, sizeof *c);
+    c->n = n_stages;
+    if (n_stages) memcpy(c->modes, modes, (size_t)n_stages);
+    sdro_chain_reset(c);
+    return c;
+}
+
+void sdro_chain_free(sdro_chain* c) { free(c); }
+
+int64_t sdro_chain_feed(sdro_chain* c, const int16_t* iq, int64_t n_cplx, int16_t* out)
+{
+    /* DownChannelizer::feed (downchannelizer.cpp:50-91) */
+    if (c->n == 0) { memcpy(out, iq, (size_t)n_cplx * 4); return n_cplx; }   /* pass-through (:57-60) */
+    const int32_t div = 1 << c->n;
+    int64_t n_out = 0;
+    for (int64_t i = 0; i < n_cplx; i++) {
+        int32_t re = iq[2*i], im = iq[2*i+1];
+        int s = 0;
+        for (; s < c->n; s++)
+            if (!hb_push(&c->st[s], &re, &im)) break;
+        if (s == c->n) {
+            out[2*n_out]   = (int16_t)(re / div);          /* s.m_real /= (1<<n): C division, toward zero */
+            out[2*n_out+1] = (int16_t)(im / div);
+            n_out++;
+        }
+    }
+    return n_out;
+}

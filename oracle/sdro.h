@@ -1,0 +1,76 @@
+/* TEST INFRASTRUCTURE -- CPU oracle ("sdro") for the sdrbase/dsp RX hot path.
+ *
+ * A from-scratch restatement, in plain C, of what the reference computes on the path named by
+ * BASELINE.json / SURVEY.md §8.  It is the checker for the HIP engine: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The product
+ * (sdrangel_amd/, libsdrx.so) never links, imports or calls anything in oracle/.
+ *
+ * Pinning: every function here is checked bit-for-bit against the reference's own classes
+ * compiled from /root/reference (oracle/ref_shim.cpp -> oracle/_ref/libsdrref.so) by
+ * tests/test_oracle_vs_ref.py (runs where the reference is present) and against the golden
+ * vectors in tests/golden/ that were generated from that same compiled reference
+ * (tests/golden/make_golden.py).  The reference itself ships no tests or vectors.
+ */
+#ifndef SDRO_H
+#define SDRO_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* fcpos coding = the device plugins' m_fcPos: 0 infradyne, 1 supradyne, 2 centre. */
+enum { SDRO_FC_INF = 0, SDRO_FC_SUP = 1, SDRO_FC_CEN = 2 };
+/* channelizer stage modes = DownChannelizer::FilterStage::Mode (downchannelizer.h:76-80). */
+enum { SDRO_MODE_CENTER = 0, SDRO_MODE_LOWER = 1, SDRO_MODE_UPPER = 2 };
+
+/* ---- Decimators<qint32,qint16,16,InputBits> (decimators.h:279-341) ---- */
+typedef struct sdro_decim sdro_decim;
+sdro_decim* sdro_decim_new(int log2_decim, int fcpos, int input_bits);
+void        sdro_decim_free(sdro_decim*);
+void        sdro_decim_reset(sdro_decim*);
+/* iq: interleaved int16 I,Q; n_int16 = number of int16 (the reference's `len`).  Whole groups
+ * only, tail dropped (decimators.h:3492).  Returns #complex outputs written to out_iq. */
+int32_t     sdro_decim_process(sdro_decim*, const int16_t* iq, int32_t n_int16, int16_t* out_iq);
+/* #int16 consumed per loop iteration of the reference function (its `pos +=` stride). */
+int32_t     sdro_decim_group_int16(int log2_decim, int fcpos);
+
+/* ---- DownChannelizer (downchannelizer.cpp:50-91,157-189,250-287) ---- */
+/* float bisection; writes up to 32 modes; returns n_stages. */
+int32_t sdro_chan_plan(int32_t in_rate, int32_t req_rate, int32_t req_fc,
+                       uint8_t* modes, int32_t* out_rate, int32_t* residual_ofs);
+typedef struct sdro_chain sdro_chain;
+sdro_chain* sdro_chain_new(int32_t n_stages, const uint8_t* modes);
+void        sdro_chain_free(sdro_chain*);
+void        sdro_chain_reset(sdro_chain*);
+int64_t     sdro_chain_feed(sdro_chain*, const int16_t* iq, int64_t n_cplx, int16_t* out_iq);
+
+/* ---- float back-end: NCO, Interpolator, g_fft, fftfilt, PhaseDiscriminators ---- */
+void    sdro_nco_table(float* tbl4096);                                  /* nco.cpp:30-39 */
+int32_t sdro_nco_inc(float freq, float rate);                            /* nco.cpp:48-52 */
+
+typedef struct sdro_backend sdro_backend;
+/* NCO(setFreq(nco_freq,in_rate)) -> Interpolator::create(phase_steps,in_rate,cutoff,tpp) ->
+ * decimate with distance += in_rate/out_rate  (nfmdemod.cpp:150-160, 453-476). */
+sdro_backend* sdro_backend_new(float nco_freq, float in_rate, float out_rate,
+                               int32_t phase_steps, float cutoff, float taps_per_phase);
+void    sdro_backend_free(sdro_backend*);
+int64_t sdro_backend_feed(sdro_backend*, const int16_t* iq, int64_t n_cplx, float* out_iq);
+int32_t sdro_backend_ntaps(const sdro_backend*);                         /* taps per phase */
+const float* sdro_backend_taps(const sdro_backend*);                     /* [phase][ntaps] */
+
+void    sdro_gfft(float* iq, int32_t n, int32_t inverse);                /* gfft.h:3308-3330 */
+
+typedef struct sdro_fftfilt sdro_fftfilt;
+sdro_fftfilt* sdro_fftfilt_new(float f1, float f2, int32_t len);         /* fftfilt.cpp:77-84,108-146 */
+void    sdro_fftfilt_free(sdro_fftfilt*);
+const float* sdro_fftfilt_filter(const sdro_fftfilt*);                   /* len complex */
+/* mode 0 runFilt, 1 runSSB usb, 2 runSSB lsb, 3 runDSB (fftfilt.cpp:261-361) */
+int64_t sdro_fftfilt_run(sdro_fftfilt*, int32_t mode, const float* in_iq, int64_t n, float* out_iq);
+
+/* kind 0: phaseDiscriminatorDelta (phasediscri.h:61-78); 1: phaseDiscriminator (:50-55) */
+void    sdro_discri(int32_t kind, float fm_scaling, const float* in_iq, int64_t n, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
