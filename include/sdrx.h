@@ -1,0 +1,163 @@
+/* sdrx -- MI355X (gfx950) engine for SDRangel's sdrbase/dsp RX hot path.
+ *
+ * C ABI of libsdrx.so.  Plain pointers and sizes only.  Every entry point names the reference
+ * interface it replaces (paths relative to the lainy/sdrangel tree, v4.0.6).
+ *
+ * Conventions
+ *   - a complex sample is the reference's `Sample` {int16 re; int16 im} packed in 4 bytes
+ *     (sdrbase/dsp/dsptypes.h:44-65); buffers of them are "iq" (interleaved I,Q int16).
+ *   - every function returns 0 on success or a negative code (SDRX_E*); nothing throws across
+ *     the ABI.  sdrx_last_error() gives the text of the calling thread's last failure.
+ *   - a handle is single-threaded (caller serialises, like one Decimators member per device
+ *     thread in the reference); different handles are independent and may sit on different GPUs.
+ *   - `*_dev` variants take device pointers and are asynchronous on the handle's HIP stream;
+ *     the host-pointer variants copy in/out and return when the result is in the caller's buffer.
+ *   - the library has NO CPU fallback: without a usable HIP device every create call fails with
+ *     SDRX_ENODEV.
+ */
+#ifndef SDRX_H
+#define SDRX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDRX_OK        0
+#define SDRX_EINVAL   -1   /* bad argument */
+#define SDRX_ENODEV   -2   /* no HIP device / device index out of range */
+#define SDRX_EHIP     -3   /* a HIP runtime call failed (text in sdrx_last_error) */
+#define SDRX_ENOMEM   -4
+#define SDRX_ESTATE   -5   /* call not valid in the handle's current state */
+
+/* fcPos of the device plugins (limesdrinputthread.cpp:103-135): which decimateK_* is called */
+#define SDRX_FC_INF 0      /* decimateK_inf */
+#define SDRX_FC_SUP 1      /* decimateK_sup */
+#define SDRX_FC_CEN 2      /* decimateK_cen */
+
+/* DownChannelizer::FilterStage::Mode (sdrbase/dsp/downchannelizer.h:76-80) */
+#define SDRX_MODE_CENTER 0
+#define SDRX_MODE_LOWER  1
+#define SDRX_MODE_UPPER  2
+
+const char* sdrx_version(void);
+const char* sdrx_last_error(void);
+int         sdrx_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Decimators<qint32, qint16, 16, InputBits>  (sdrbase/dsp/decimators.h:279-341)
+ * One handle == one `m_decimators` member used with ONE (log2, fcpos) -- the reference keeps the
+ * six half-band states inside the object (decimators.h:326-340); so does the handle.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sdrx_decim sdrx_decim_t;
+
+/* log2_decim 0..6, fcpos SDRX_FC_*, input_bits 8|12|16 (decimation_shifts<16,InputBits>,
+ * decimators.h:25-185). */
+int sdrx_decim_create(sdrx_decim_t** out, int device, int log2_decim, int fcpos, int input_bits);
+int sdrx_decim_destroy(sdrx_decim_t* h);
+/* zero filter state == a freshly constructed Decimators object */
+int sdrx_decim_reset(sdrx_decim_t* h);
+
+/* Replaces  m_decimators.decimateK_{inf,sup,cen}(&it, buf, len)  (decimators.h:463-3885):
+ * `iq`/`n_int16` are the reference's `buf`/`len`; whole groups only, a trailing partial group
+ * is dropped and NOT carried (decimators.h:3492); state is carried across calls.
+ * out_iq must hold n_int16/2 >> log2 complex samples; *n_out_cplx = how far `it` advanced. */
+int sdrx_decim_process(sdrx_decim_t* h, const int16_t* iq, int32_t n_int16,
+                       int16_t* out_iq, int32_t* n_out_cplx);
+
+/* Same contract on device-resident buffers, asynchronous on the handle's stream.
+ * d_iq must be 16-byte aligned. */
+int sdrx_decim_process_dev(sdrx_decim_t* h, const int16_t* d_iq, int64_t n_int16,
+                           int16_t* d_out_iq, int64_t* n_out_cplx);
+int sdrx_decim_sync(sdrx_decim_t* h);
+/* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = handle's own stream */
+int sdrx_decim_set_stream(sdrx_decim_t* h, void* hip_stream);
+/* #int16 consumed per loop iteration of the matching reference function (its `pos +=`) */
+int sdrx_decim_group_int16(int log2_decim, int fcpos);
+/* checkpoint of the carried state (the last `sdrx_decim_state_bytes()` bytes of consumed input;
+ * the six ring buffers of the reference are a pure function of it) */
+int64_t sdrx_decim_state_bytes(const sdrx_decim_t* h);
+int sdrx_decim_get_state(sdrx_decim_t* h, void* host_buf);
+int sdrx_decim_set_state(sdrx_decim_t* h, const void* host_buf);
+/* HIP-event timing of the chain kernel itself, on the stream it is launched on: when enabled every
+ * process call brackets its main kernel with two events; get_timing synchronises the stream and
+ * returns the summed kernel time and launch count since the last reset. */
+int sdrx_decim_set_timing(sdrx_decim_t* h, int enabled);
+int sdrx_decim_get_timing(sdrx_decim_t* h, double* total_ms, int64_t* launches, int reset);
+/* name + launch geometry of the kernel the last process call launched (for profiling/bench) */
+int sdrx_decim_last_launch(const sdrx_decim_t* h, char* kernel_name, int name_cap,
+                           int* grid, int* block, int* lds_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * DownChannelizer bank  (sdrbase/dsp/downchannelizer.{h,cpp}) -- N channels fed from ONE device
+ * stream.  Replaces N x { ThreadedBasebandSampleSink::feed -> DownChannelizer::feed }
+ * (threadedbasebandsamplesink.cpp:114-119, downchannelizer.cpp:50-91): the input is read once and
+ * every distinct prefix of the channels' half-band chains is evaluated once.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sdrx_chan_bank sdrx_chan_bank_t;
+
+/* Runs DownChannelizer::applyConfiguration's float bisection (downchannelizer.cpp:157-189,
+ * 250-287) per channel: req_rate[c]/req_fc[c] are the DSPConfigureChannelizer arguments. */
+int sdrx_chan_bank_create(sdrx_chan_bank_t** out, int device, int32_t in_rate, int32_t n_ch,
+                          const int32_t* req_rate, const int32_t* req_fc);
+int sdrx_chan_bank_destroy(sdrx_chan_bank_t* h);
+/* per-channel result of the bisection == what MsgChannelizerNotification reports
+ * (downchannelizer.cpp:184-187); modes[] gets n_stages entries (cap 32). */
+int sdrx_chan_bank_info(const sdrx_chan_bank_t* h, int32_t ch, int32_t* n_stages, uint8_t* modes,
+                        int32_t* out_rate, int32_t* residual_ofs);
+/* the bisection alone, no device needed (host logic) */
+int sdrx_chan_plan(int32_t in_rate, int32_t req_rate, int32_t req_fc,
+                   uint8_t* modes, int32_t* out_rate, int32_t* residual_ofs);
+/* DSPConfigureChannelizer for one channel: chain rebuilt with ZERO history
+ * (downchannelizer.cpp:167-171 frees and recreates the stages). */
+int sdrx_chan_bank_reconfigure(sdrx_chan_bank_t* h, int32_t ch, int32_t req_rate, int32_t req_fc);
+int sdrx_chan_bank_reset(sdrx_chan_bank_t* h);
+
+/* Replaces DownChannelizer::feed(begin, end, positiveOnly) for every channel of the bank.  Any
+ * n_cplx; decimation phase is carried across calls (no drop).  Outputs accumulate in per-channel
+ * device queues until read. */
+int sdrx_chan_bank_feed(sdrx_chan_bank_t* h, const int16_t* iq, int64_t n_cplx);
+int sdrx_chan_bank_feed_dev(sdrx_chan_bank_t* h, const int16_t* d_iq, int64_t n_cplx);
+/* number of complex outputs of channel ch waiting to be read */
+int64_t sdrx_chan_bank_available(sdrx_chan_bank_t* h, int32_t ch);
+/* == the m_sampleBuffer handed to m_sampleSink->feed (downchannelizer.cpp:87): copies up to cap
+ * complex samples of channel ch to host memory and removes them; returns the count (<0: error) */
+int64_t sdrx_chan_bank_read(sdrx_chan_bank_t* h, int32_t ch, int16_t* out_iq, int64_t cap);
+/* device-side view of what the last feed produced for channel ch (valid until the next feed) */
+int sdrx_chan_bank_last_dev(sdrx_chan_bank_t* h, int32_t ch, const int16_t** d_out_iq, int64_t* n_cplx);
+int sdrx_chan_bank_sync(sdrx_chan_bank_t* h);
+int sdrx_chan_bank_set_stream(sdrx_chan_bank_t* h, void* hip_stream);
+/* as sdrx_decim_set_timing: brackets each feed's tree_kernel launches (all passes) */
+int sdrx_chan_bank_set_timing(sdrx_chan_bank_t* h, int enabled);
+int sdrx_chan_bank_get_timing(sdrx_chan_bank_t* h, double* total_ms, int64_t* feeds, int reset);
+int sdrx_chan_bank_last_launch(const sdrx_chan_bank_t* h, char* kernel_name, int name_cap,
+                               int* grid, int* block, int* lds_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * SampleSinkFifo (sdrbase/dsp/samplesinkfifo.{h,cpp}) -- host ring of `Sample`, same
+ * write / readBegin / readCommit contract, minus the Qt signal (a callback instead of dataReady()).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sdrx_fifo sdrx_fifo_t;
+typedef void (*sdrx_fifo_data_ready_cb)(void* user);
+int      sdrx_fifo_create(sdrx_fifo_t** out, uint32_t size_samples);          /* SampleSinkFifo(int) + setSize */
+int      sdrx_fifo_destroy(sdrx_fifo_t* f);
+int      sdrx_fifo_set_size(sdrx_fifo_t* f, uint32_t size_samples);           /* setSize: also empties */
+uint32_t sdrx_fifo_size(sdrx_fifo_t* f);
+uint32_t sdrx_fifo_fill(sdrx_fifo_t* f);
+void     sdrx_fifo_on_data_ready(sdrx_fifo_t* f, sdrx_fifo_data_ready_cb cb, void* user);
+/* write(const quint8* data, uint count) (samplesinkfifo.cpp:70-111): count in BYTES, returns samples written */
+uint32_t sdrx_fifo_write_bytes(sdrx_fifo_t* f, const uint8_t* data, uint32_t count_bytes);
+/* write(begin, end) (samplesinkfifo.cpp:113-153): count in samples */
+uint32_t sdrx_fifo_write(sdrx_fifo_t* f, const int16_t* iq, uint32_t count_samples);
+/* read(begin, end) (samplesinkfifo.cpp:155-191) */
+uint32_t sdrx_fifo_read(sdrx_fifo_t* f, int16_t* iq, uint32_t count_samples);
+/* readBegin / readCommit (samplesinkfifo.cpp:193-231): two spans as offsets into the ring */
+uint32_t sdrx_fifo_read_begin(sdrx_fifo_t* f, uint32_t count, const int16_t** part1, uint32_t* n1,
+                              const int16_t** part2, uint32_t* n2);
+uint32_t sdrx_fifo_read_commit(sdrx_fifo_t* f, uint32_t count);
+/* samples dropped by overflowing writes since creation (the reference only logs them) */
+uint64_t sdrx_fifo_dropped(sdrx_fifo_t* f);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDRX_H */

@@ -1,0 +1,322 @@
+"""sdrangel_amd -- ctypes face of libsdrx.so (the MI355X engine for SDRangel's sdrbase/dsp RX path).
+
+The product is the C-ABI shared library (include/sdrx.h); this module only loads it and gives
+tests / bench.py numpy-friendly wrappers whose names follow the reference classes
+(`Decimators`, `DownChannelizer` bank, `SampleSinkFifo`).  There is no CPU fallback: if the
+library is missing, or no HIP device is present when a GPU object is created, it raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdrx.so")
+
+FC_INF, FC_SUP, FC_CEN = 0, 1, 2
+MODE_CENTER, MODE_LOWER, MODE_UPPER = 0, 1, 2
+
+_lib = None
+
+
+class SdrxError(RuntimeError):
+    pass
+
+
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels carry a private libamdhip64.so with the
+    same SONAME (libamdhip64.so.7) as /opt/rocm's.  If libsdrx.so pulled in ROCm's copy first and
+    torch its own later, the process would hold two runtimes and the second would see no GPU.
+    Loading torch's copy first (by path, without importing torch) makes both resolve to it."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
+def lib() -> C.CDLL:
+    """Load libsdrx.so (built in-tree by `make -C sdrangel_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SdrxError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    _share_hip_runtime_with_torch()
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
+    pp = C.POINTER(C.c_void_p)
+    sig = {
+        "sdrx_version": (C.c_char_p, []),
+        "sdrx_last_error": (C.c_char_p, []),
+        "sdrx_device_count": (C.c_int, []),
+        "sdrx_decim_create": (C.c_int, [pp, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "sdrx_decim_destroy": (C.c_int, [vp]),
+        "sdrx_decim_reset": (C.c_int, [vp]),
+        "sdrx_decim_process": (C.c_int, [vp, vp, i32, vp, C.POINTER(i32)]),
+        "sdrx_decim_process_dev": (C.c_int, [vp, vp, i64, vp, C.POINTER(i64)]),
+        "sdrx_decim_sync": (C.c_int, [vp]),
+        "sdrx_decim_set_stream": (C.c_int, [vp, vp]),
+        "sdrx_decim_group_int16": (C.c_int, [C.c_int, C.c_int]),
+        "sdrx_decim_state_bytes": (i64, [vp]),
+        "sdrx_decim_get_state": (C.c_int, [vp, vp]),
+        "sdrx_decim_set_state": (C.c_int, [vp, vp]),
+        "sdrx_decim_set_timing": (C.c_int, [vp, C.c_int]),
+        "sdrx_decim_get_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i64), C.c_int]),
+        "sdrx_decim_last_launch": (C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "sdrx_chan_bank_create": (C.c_int, [pp, C.c_int, i32, i32, vp, vp]),
+        "sdrx_chan_bank_destroy": (C.c_int, [vp]),
+        "sdrx_chan_bank_info": (C.c_int, [vp, i32, C.POINTER(i32), vp, C.POINTER(i32), C.POINTER(i32)]),
+        "sdrx_chan_plan": (C.c_int, [i32, i32, i32, vp, C.POINTER(i32), C.POINTER(i32)]),
+        "sdrx_chan_bank_reconfigure": (C.c_int, [vp, i32, i32, i32]),
+        "sdrx_chan_bank_reset": (C.c_int, [vp]),
+        "sdrx_chan_bank_feed": (C.c_int, [vp, vp, i64]),
+        "sdrx_chan_bank_feed_dev": (C.c_int, [vp, vp, i64]),
+        "sdrx_chan_bank_available": (i64, [vp, i32]),
+        "sdrx_chan_bank_read": (i64, [vp, i32, vp, i64]),
+        "sdrx_chan_bank_last_dev": (C.c_int, [vp, i32, pp, C.POINTER(i64)]),
+        "sdrx_chan_bank_sync": (C.c_int, [vp]),
+        "sdrx_chan_bank_set_stream": (C.c_int, [vp, vp]),
+        "sdrx_chan_bank_set_timing": (C.c_int, [vp, C.c_int]),
+        "sdrx_chan_bank_get_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i64), C.c_int]),
+        "sdrx_chan_bank_last_launch": (C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "sdrx_fifo_create": (C.c_int, [pp, u32]),
+        "sdrx_fifo_destroy": (C.c_int, [vp]),
+        "sdrx_fifo_set_size": (C.c_int, [vp, u32]),
+        "sdrx_fifo_size": (u32, [vp]),
+        "sdrx_fifo_fill": (u32, [vp]),
+        "sdrx_fifo_write_bytes": (u32, [vp, vp, u32]),
+        "sdrx_fifo_write": (u32, [vp, vp, u32]),
+        "sdrx_fifo_read": (u32, [vp, vp, u32]),
+        "sdrx_fifo_read_begin": (u32, [vp, u32, pp, C.POINTER(u32), pp, C.POINTER(u32)]),
+        "sdrx_fifo_read_commit": (u32, [vp, u32]),
+        "sdrx_fifo_dropped": (C.c_uint64, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)          # AttributeError here == the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+#: every symbol include/sdrx.h declares (checked against the built library by tests/test_abi.py)
+def exported_symbols(header_path: str | None = None) -> list[str]:
+    import re
+    header_path = header_path or os.path.join(os.path.dirname(_HERE), "include", "sdrx.h")
+    txt = open(header_path).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sdrx_[a-z0-9_]+)\s*\(", txt)) - {"sdrx_fifo_data_ready_cb"})
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise SdrxError(f"{what}: rc={rc}: {lib().sdrx_last_error().decode()}")
+
+
+def _i16(a) -> np.ndarray:
+    a = np.ascontiguousarray(a)
+    if a.dtype != np.int16:
+        raise TypeError("expected int16 I/Q")
+    return a
+
+
+class Decimators:
+    """Decimators<qint32, qint16, 16, input_bits> used with one (log2, fcpos)
+    (sdrbase/dsp/decimators.h:279-341).  `decimate(buf)` == decimateK_{inf,sup,cen}(&it, buf, len)."""
+
+    def __init__(self, log2_decim: int, fcpos: int = FC_CEN, input_bits: int = 12, device: int = 0):
+        self._h = C.c_void_p()
+        _check(lib().sdrx_decim_create(C.byref(self._h), device, log2_decim, fcpos, input_bits), "sdrx_decim_create")
+        self.log2, self.fcpos, self.input_bits = log2_decim, fcpos, input_bits
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sdrx_decim_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def reset(self):
+        _check(lib().sdrx_decim_reset(self._h), "sdrx_decim_reset")
+
+    def decimate(self, buf) -> np.ndarray:
+        """buf: int16 interleaved I,Q (len = reference `len`).  Returns int16 array of 2*n_out."""
+        buf = _i16(buf)
+        out = np.empty(max(2 * ((buf.size // 2) >> self.log2), 2), np.int16)
+        n = C.c_int32()
+        _check(lib().sdrx_decim_process(self._h, buf.ctypes.data, buf.size, out.ctypes.data, C.byref(n)), "sdrx_decim_process")
+        return out[: 2 * n.value]
+
+    def decimate_dev(self, d_in_ptr: int, n_int16: int, d_out_ptr: int) -> int:
+        """device pointers; asynchronous on the handle's stream; returns #complex outputs"""
+        n = C.c_int64()
+        _check(lib().sdrx_decim_process_dev(self._h, d_in_ptr, n_int16, d_out_ptr, C.byref(n)), "sdrx_decim_process_dev")
+        return n.value
+
+    def sync(self):
+        _check(lib().sdrx_decim_sync(self._h), "sdrx_decim_sync")
+
+    def set_stream(self, hip_stream: int | None):
+        _check(lib().sdrx_decim_set_stream(self._h, hip_stream), "sdrx_decim_set_stream")
+
+    def set_timing(self, on: bool):
+        _check(lib().sdrx_decim_set_timing(self._h, int(on)), "sdrx_decim_set_timing")
+
+    def get_timing(self, reset: bool = True):
+        """(total kernel ms, launches) measured with HIP events on the launch stream"""
+        ms, n = C.c_double(), C.c_int64()
+        _check(lib().sdrx_decim_get_timing(self._h, C.byref(ms), C.byref(n), int(reset)), "sdrx_decim_get_timing")
+        return ms.value, n.value
+
+    def get_state(self) -> bytes:
+        nb = lib().sdrx_decim_state_bytes(self._h)
+        buf = C.create_string_buffer(nb)
+        _check(lib().sdrx_decim_get_state(self._h, buf), "sdrx_decim_get_state")
+        return buf.raw
+
+    def set_state(self, state: bytes):
+        if len(state) != lib().sdrx_decim_state_bytes(self._h):
+            raise ValueError("state size")
+        _check(lib().sdrx_decim_set_state(self._h, state), "sdrx_decim_set_state")
+
+    def last_launch(self) -> dict:
+        name = C.create_string_buffer(128)
+        g, b, l = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().sdrx_decim_last_launch(self._h, name, 128, C.byref(g), C.byref(b), C.byref(l)), "last_launch")
+        return {"kernel": name.value.decode(), "grid": g.value, "block": b.value, "lds_bytes": l.value}
+
+
+def chan_plan(in_rate: int, req_rate: int, req_fc: int):
+    """DownChannelizer::applyConfiguration's float bisection -> (modes, out_rate, residual_ofs)."""
+    modes = np.zeros(32, np.uint8)
+    r, f = C.c_int32(), C.c_int32()
+    n = lib().sdrx_chan_plan(in_rate, req_rate, req_fc, modes.ctypes.data, C.byref(r), C.byref(f))
+    if n < 0:
+        raise SdrxError(f"sdrx_chan_plan rc={n}")
+    return modes[:n].copy(), r.value, f.value
+
+
+class ChannelizerBank:
+    """N x DownChannelizer fed from one device stream (sdrbase/dsp/downchannelizer.{h,cpp})."""
+
+    def __init__(self, in_rate: int, req_rates, req_fcs, device: int = 0):
+        rr = np.ascontiguousarray(req_rates, dtype=np.int32)
+        fc = np.ascontiguousarray(req_fcs, dtype=np.int32)
+        assert rr.size == fc.size
+        self.n_ch = int(rr.size)
+        self._h = C.c_void_p()
+        _check(lib().sdrx_chan_bank_create(C.byref(self._h), device, in_rate, self.n_ch, rr.ctypes.data, fc.ctypes.data),
+               "sdrx_chan_bank_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sdrx_chan_bank_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def info(self, ch: int):
+        n, r, f = C.c_int32(), C.c_int32(), C.c_int32()
+        modes = np.zeros(32, np.uint8)
+        _check(lib().sdrx_chan_bank_info(self._h, ch, C.byref(n), modes.ctypes.data, C.byref(r), C.byref(f)), "sdrx_chan_bank_info")
+        return modes[: n.value].copy(), r.value, f.value
+
+    def reconfigure(self, ch: int, req_rate: int, req_fc: int):
+        _check(lib().sdrx_chan_bank_reconfigure(self._h, ch, req_rate, req_fc), "sdrx_chan_bank_reconfigure")
+
+    def reset(self):
+        _check(lib().sdrx_chan_bank_reset(self._h), "sdrx_chan_bank_reset")
+
+    def feed(self, iq):
+        iq = _i16(iq)
+        _check(lib().sdrx_chan_bank_feed(self._h, iq.ctypes.data, iq.size // 2), "sdrx_chan_bank_feed")
+
+    def feed_dev(self, d_ptr: int, n_cplx: int):
+        _check(lib().sdrx_chan_bank_feed_dev(self._h, d_ptr, n_cplx), "sdrx_chan_bank_feed_dev")
+
+    def available(self, ch: int) -> int:
+        return lib().sdrx_chan_bank_available(self._h, ch)
+
+    def read(self, ch: int, cap: int | None = None) -> np.ndarray:
+        cap = self.available(ch) if cap is None else cap
+        out = np.empty(max(2 * cap, 2), np.int16)
+        n = lib().sdrx_chan_bank_read(self._h, ch, out.ctypes.data, cap)
+        if n < 0:
+            raise SdrxError(f"sdrx_chan_bank_read rc={n}: {lib().sdrx_last_error().decode()}")
+        return out[: 2 * n]
+
+    def sync(self):
+        _check(lib().sdrx_chan_bank_sync(self._h), "sdrx_chan_bank_sync")
+
+    def set_stream(self, hip_stream: int | None):
+        _check(lib().sdrx_chan_bank_set_stream(self._h, hip_stream), "sdrx_chan_bank_set_stream")
+
+    def set_timing(self, on: bool):
+        _check(lib().sdrx_chan_bank_set_timing(self._h, int(on)), "sdrx_chan_bank_set_timing")
+
+    def get_timing(self, reset: bool = True):
+        ms, n = C.c_double(), C.c_int64()
+        _check(lib().sdrx_chan_bank_get_timing(self._h, C.byref(ms), C.byref(n), int(reset)), "sdrx_chan_bank_get_timing")
+        return ms.value, n.value
+
+    def last_launch(self) -> dict:
+        name = C.create_string_buffer(128)
+        g, b, l = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().sdrx_chan_bank_last_launch(self._h, name, 128, C.byref(g), C.byref(b), C.byref(l)), "last_launch")
+        return {"kernel": name.value.decode(), "grid": g.value, "block": b.value, "lds_bytes": l.value}
+
+
+class SampleSinkFifo:
+    """sdrbase/dsp/samplesinkfifo.{h,cpp}: write / read / readBegin / readCommit."""
+
+    def __init__(self, size: int):
+        self._h = C.c_void_p()
+        _check(lib().sdrx_fifo_create(C.byref(self._h), size), "sdrx_fifo_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sdrx_fifo_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def set_size(self, size: int):
+        _check(lib().sdrx_fifo_set_size(self._h, size), "sdrx_fifo_set_size")
+
+    size = property(lambda self: lib().sdrx_fifo_size(self._h))
+    fill = property(lambda self: lib().sdrx_fifo_fill(self._h))
+    dropped = property(lambda self: lib().sdrx_fifo_dropped(self._h))
+
+    def write(self, iq) -> int:
+        iq = _i16(iq)
+        return lib().sdrx_fifo_write(self._h, iq.ctypes.data, iq.size // 2)
+
+    def write_bytes(self, data: bytes) -> int:
+        return lib().sdrx_fifo_write_bytes(self._h, data, len(data))
+
+    def read(self, count: int) -> np.ndarray:
+        out = np.empty(max(2 * count, 2), np.int16)
+        n = lib().sdrx_fifo_read(self._h, out.ctypes.data, count)
+        return out[: 2 * n]
+
+    def read_begin(self, count: int):
+        p1, p2, n1, n2 = C.c_void_p(), C.c_void_p(), C.c_uint32(), C.c_uint32()
+        tot = lib().sdrx_fifo_read_begin(self._h, count, C.byref(p1), C.byref(n1), C.byref(p2), C.byref(n2))
+
+        def view(p, n):
+            if not n:
+                return np.empty(0, np.int16)
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int16)), shape=(2 * n,)).copy()
+
+        return tot, view(p1, n1.value), view(p2, n2.value)
+
+    def read_commit(self, count: int) -> int:
+        return lib().sdrx_fifo_read_commit(self._h, count)

@@ -1,0 +1,669 @@
+// libsdrx.so: sdrx_chan_* -- a bank of DownChannelizers fed from one device stream
+// (reference: sdrbase/dsp/downchannelizer.{h,cpp}).  Host planner + launches; kernel in tree_kernel.hpp.
+#include "sdrx_common.hpp"
+#include "tree_kernel.hpp"
+#include <vector>
+#include <array>
+#include <cstring>
+#include <cstdlib>
+#include <new>
+#include <algorithm>
+
+using namespace sdrx;
+
+/* ------------------------------------------------------------------ the float bisection
+ * DownChannelizer::applyConfiguration / createFilterChain (downchannelizer.cpp:157-189, 250-287),
+ * restated.  All interval arithmetic is float32 (`Real`); the reference writes `x / 2.0` in two
+ * places, which is evaluated in double and rounded to float when passed on -- kept.               */
+static bool contains(float ss, float se, float cs, float ce)
+{
+    if (se <= ss || ce <= cs) return false;               // signalContainsChannel (:240-248)
+    return ss <= cs && se >= ce;
+}
+
+static int plan_chain(int32_t in_rate, int32_t req_rate, int32_t req_fc, uint8_t* modes, int cap,
+                      int32_t* out_rate, int32_t* ofs_out)
+{
+    if (in_rate == 0) { *out_rate = 0; *ofs_out = 0; return 0; }   // "m_inputSampleRate=0 aborting"
+    float s = (float)(in_rate / -2), e = (float)(in_rate / 2);
+    const float cs = (float)(req_fc - req_rate / 2), ce = (float)(req_fc + req_rate / 2);
+    int n = 0;
+    while (n < cap) {
+        const float bw = e - s, rot = bw / 4;
+        const float mid_lo = (float)((double)s + (double)bw / 2.0);       // sigStart + sigBw / 2.0
+        const float mid_hi = e - bw / 2.0f;                               // sigEnd - sigBw / 2.0f
+        if (contains(s, mid_lo, cs, ce)) { modes[n++] = SDRX_MODE_LOWER; e = mid_lo; continue; }
+        if (contains(mid_hi, e, cs, ce)) { modes[n++] = SDRX_MODE_UPPER; s = mid_hi; continue; }
+        const float cs2 = s + rot, ce2 = e - rot;
+        if (contains(cs2, ce2, cs, ce)) { modes[n++] = SDRX_MODE_CENTER; s = cs2; e = ce2; continue; }
+        break;
+    }
+    const float ofs = (float)(((double)(ce - cs) / 2.0 + (double)cs) - ((double)(e - s) / 2.0 + (double)s));
+    *ofs_out = (int32_t)ofs;                               // Real -> int m_currentCenterFrequency
+    *out_rate = in_rate / (1 << n);
+    return n;
+}
+
+/* ------------------------------------------------------------------ host-side plan of one group */
+namespace {
+
+constexpr int MAX_STAGES = 30;
+constexpr int LDS_BUDGET_DW = 64 * 1024 / 4 - 64;          // two workgroups per CU
+constexpr int LDS_HARD_DW = 150 * 1024 / 4;
+
+struct HNode {
+    int parent = -1, mode = 0, depth = 0;
+    int child[3] = { -1, -1, -1 };
+    std::vector<int> ends;        // bank channel ids whose chain ends here
+    int stream = -1;              // index into Group::streams if this node's output is a global stream
+};
+
+struct Channel {
+    int32_t req_rate = 0, req_fc = 0, out_rate = 0, ofs = 0;
+    int n = 0;
+    uint8_t modes[32] = { 0 };
+    int group = -1;               // -1: pass-through (0 stages) or dead
+    bool passthrough = false;
+    DevBuf out;                   // device queue of packed Samples
+    int64_t avail = 0;            // complex samples queued
+    int64_t last_off = 0, last_n = 0;
+    int sink = -1;                // sink index inside its group
+};
+
+struct Stream {
+    int trie_node = 0, depth = 0, pass = 0, subtree = -1;
+    uint32_t* hist[2] = { nullptr, nullptr };
+    int cur = 0;
+    DevBuf mid;                   // new samples of a node stream (unused for the raw stream)
+    int sink = -1;                // sink (in the producing pass) that fills `mid`
+};
+
+struct SinkInfo { int kind; int ch; int stream; int depth; int next; };   // kind 0 channel, 1 node stream
+
+struct Group {
+    int index = -1;               // position in sdrx_chan_bank::groups
+    int64_t T = 0;                // samples fed since this group's epoch
+    std::vector<int> chans;
+    std::vector<HNode> trie;
+    std::vector<Stream> streams;  // [0] = the raw stream
+    std::vector<std::vector<int>> passes;
+    std::vector<TkSubtree> subtrees;
+    std::vector<TkNode> nodes;
+    std::vector<TkArray> arrays;
+    std::vector<SinkInfo> sinks;
+    int max_lds_dw = 0;
+    void* d_static = nullptr;     // subtrees | nodes | arrays
+    TkSubtree* d_subtrees = nullptr; TkNode* d_nodes = nullptr; TkArray* d_arrays = nullptr;
+};
+
+int arm_len(int rel_depth) { return HIST / 2 + (TK_CHUNK >> (rel_depth + 2)); }   // dwords
+
+// LDS dwords a subtree of `levels` levels below trie node `root` needs
+int subtree_lds(const std::vector<HNode>& trie, int root, int levels, int* n_nodes_out)
+{
+    int lds = 0, n_nodes = 0;
+    std::vector<int> cur{ root };
+    for (int rel = 0; rel < levels; rel++) {
+        std::vector<int> nxt;
+        for (int id : cur) {
+            bool c = trie[id].child[0] >= 0, lu = trie[id].child[1] >= 0 || trie[id].child[2] >= 0;
+            if (!c && !lu) continue;
+            lds += arm_len(rel) * (2 + (c ? 2 : 0) + (lu ? 2 : 0));
+            for (int m = 0; m < 3; m++) if (trie[id].child[m] >= 0) nxt.push_back(trie[id].child[m]);
+        }
+        n_nodes += (int)nxt.size();
+        cur.swap(nxt);
+        if (cur.empty()) break;
+    }
+    *n_nodes_out = n_nodes;
+    return lds + n_nodes * 16;
+}
+
+int height(const std::vector<HNode>& trie, int id)
+{
+    int h = 0;
+    for (int m = 0; m < 3; m++) if (trie[id].child[m] >= 0) h = std::max(h, 1 + height(trie, trie[id].child[m]));
+    return h;
+}
+
+} // namespace
+
+struct sdrx_chan_bank {
+    int device = 0, cus = 256;
+    int32_t in_rate = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::vector<Channel> ch;
+    std::vector<Group*> groups;
+    DevBuf stage_in;              // host-pointer feeds are staged here
+    DevBuf scratch;               // queue compaction
+    // per-feed dynamic tables: pinned host ring + device copies
+    static constexpr int RING = 4;
+    void* h_dyn[RING] = { nullptr, nullptr, nullptr, nullptr };
+    void* d_dyn[RING] = { nullptr, nullptr, nullptr, nullptr };
+    size_t dyn_cap[RING] = { 0, 0, 0, 0 };
+    hipEvent_t dyn_ev[RING] = { nullptr, nullptr, nullptr, nullptr };
+    int dyn_next = 0;
+    char last_name[96] = "";
+    int last_grid = 0, last_block = 0, last_lds = 0;
+    EventTimer timer;
+};
+
+static void free_group(Group* g)
+{
+    if (!g) return;
+    for (auto& s : g->streams) { for (int i = 0; i < 2; i++) if (s.hist[i]) (void)hipFree(s.hist[i]); s.mid.release(); }
+    if (g->d_static) (void)hipFree(g->d_static);
+    delete g;
+}
+
+// Build trie, cut into passes, lay out LDS, fill the static device tables.
+static int plan_group(sdrx_chan_bank* b, Group* g)
+{
+    g->trie.clear(); g->trie.emplace_back();
+    for (int c : g->chans) {
+        Channel& ch = b->ch[c];
+        int id = 0;
+        for (int s = 0; s < ch.n; s++) {
+            const int m = ch.modes[s];
+            if (g->trie[id].child[m] < 0) {
+                HNode nn; nn.parent = id; nn.mode = m; nn.depth = s + 1;
+                g->trie.push_back(nn);
+                g->trie[id].child[m] = (int)g->trie.size() - 1;
+            }
+            id = g->trie[id].child[m];
+        }
+        g->trie[id].ends.push_back(c);
+    }
+
+    g->streams.clear(); g->passes.clear(); g->subtrees.clear(); g->nodes.clear(); g->arrays.clear(); g->sinks.clear();
+    { Stream raw; raw.trie_node = 0; raw.depth = 0; raw.pass = 0; g->streams.push_back(std::move(raw)); g->trie[0].stream = 0; }
+
+    for (size_t si = 0; si < g->streams.size(); si++) {
+        const int root = g->streams[si].trie_node, pass = g->streams[si].pass;
+        const int h = height(g->trie, root);
+        if (h == 0) { g->streams[si].subtree = -1; continue; }
+        int levels = 1, nn = 0;
+        while (levels < std::min(h, TK_MAX_LEVELS) && subtree_lds(g->trie, root, levels + 1, &nn) <= LDS_BUDGET_DW) levels++;
+        int lds_need = subtree_lds(g->trie, root, levels, &nn);
+        if (lds_need > LDS_HARD_DW) { set_error("channel tree does not fit LDS"); return SDRX_EINVAL; }
+
+        TkSubtree st; memset(&st, 0, sizeof st);
+        st.n_levels = levels;
+        st.node_base = (int)g->nodes.size();
+        st.array_base = (int)g->arrays.size();
+        int off = 0;
+        struct Arms { int E[2], O[2], A[2]; };
+        auto alloc_arms = [&](int id, int rel, bool inner) {
+            Arms a; a.E[0] = a.E[1] = a.O[0] = a.O[1] = a.A[0] = a.A[1] = -1;
+            const bool c = g->trie[id].child[0] >= 0, lu = g->trie[id].child[1] >= 0 || g->trie[id].child[2] >= 0;
+            if (!inner || (!c && !lu)) return a;
+            const int len = arm_len(rel);
+            auto take = [&]() { int o = off; off += len; g->arrays.push_back(TkArray{ o, len }); return o; };
+            a.E[0] = take(); a.E[1] = take();
+            if (c) { a.O[0] = take(); a.O[1] = take(); }
+            if (lu) { a.A[0] = take(); a.A[1] = take(); }
+            return a;
+        };
+        std::vector<int> cur{ root };
+        std::vector<Arms> cur_arms{ alloc_arms(root, 0, true) };
+        st.rootE_I = cur_arms[0].E[0]; st.rootE_Q = cur_arms[0].E[1];
+        st.rootO_I = cur_arms[0].O[0]; st.rootO_Q = cur_arms[0].O[1];
+        st.rootA_I = cur_arms[0].A[0]; st.rootA_Q = cur_arms[0].A[1];
+        int rel_nodes = 0;
+        for (int rel = 1; rel <= levels; rel++) {
+            std::vector<int> nxt; std::vector<Arms> nxt_arms;
+            TkLevel& lv = st.lv[rel - 1];
+            lv.node_base = rel_nodes;
+            lv.nout = TK_CHUNK >> rel;
+            int jl = 0; while ((8 << jl) < lv.nout) jl++;
+            lv.jobs_log2 = jl;
+            for (size_t pi = 0; pi < cur.size(); pi++) {
+                for (int m = 0; m < 3; m++) {
+                    const int id = g->trie[cur[pi]].child[m];
+                    if (id < 0) continue;
+                    const Arms& pa = cur_arms[pi];
+                    const Arms own = alloc_arms(id, rel, rel < levels);
+                    TkNode nd; memset(&nd, 0xff, sizeof nd);
+                    if (m == SDRX_MODE_CENTER) {
+                        nd.oddI = pa.O[0]; nd.oddQ = pa.O[1]; nd.cenI = pa.E[0]; nd.cenQ = pa.E[1];
+                        nd.cIe = pk16(0, 2048); nd.cIo = pk16(2048, 0); nd.cQe = pk16(0, 2048); nd.cQo = pk16(2048, 0);
+                    } else {
+                        nd.oddI = pa.A[0]; nd.oddQ = pa.A[1]; nd.cenI = pa.E[1]; nd.cenQ = pa.E[0];   // I <- eQ, Q <- eI
+                        const int sg = m == SDRX_MODE_LOWER ? 1 : -1;
+                        // lower: k odd -> (-im, re), k even -> (im, -re); upper: the negation
+                        nd.cIo = pk16(-2048 * sg, 0); nd.cQo = pk16(2048 * sg, 0);
+                        nd.cIe = pk16(0, 2048 * sg);  nd.cQe = pk16(0, -2048 * sg);
+                    }
+                    nd.outE_I = own.E[0]; nd.outE_Q = own.E[1];
+                    nd.outO_I = own.O[0]; nd.outO_Q = own.O[1];
+                    nd.outA_I = own.A[0]; nd.outA_Q = own.A[1];
+                    nd.sink = -1; nd.pad = 0;
+                    // sinks: channel ends, and a node stream if the tree continues below this pass
+                    for (int c : g->trie[id].ends) {
+                        SinkInfo sk{ 0, c, -1, g->trie[id].depth, nd.sink };
+                        g->sinks.push_back(sk); nd.sink = (int)g->sinks.size() - 1;
+                        b->ch[c].sink = nd.sink;
+                    }
+                    const bool has_kids = g->trie[id].child[0] >= 0 || g->trie[id].child[1] >= 0 || g->trie[id].child[2] >= 0;
+                    if (rel == levels && has_kids) {
+                        Stream ms; ms.trie_node = id; ms.depth = g->trie[id].depth; ms.pass = pass + 1;
+                        SinkInfo sk{ 1, -1, (int)g->streams.size(), g->trie[id].depth, nd.sink };
+                        g->sinks.push_back(sk); nd.sink = (int)g->sinks.size() - 1;
+                        ms.sink = nd.sink;
+                        g->trie[id].stream = (int)g->streams.size();
+                        g->streams.push_back(std::move(ms));
+                    }
+                    g->nodes.push_back(nd);
+                    nxt.push_back(id); nxt_arms.push_back(own);
+                    rel_nodes++;
+                }
+            }
+            lv.n_nodes = (int)nxt.size();
+            cur.swap(nxt); cur_arms.swap(nxt_arms);
+        }
+        st.n_nodes = rel_nodes;
+        st.n_arrays = (int)g->arrays.size() - st.array_base;
+        st.node_tab = off;
+        st.lds_dwords = off + rel_nodes * 16;
+        g->max_lds_dw = std::max(g->max_lds_dw, st.lds_dwords);
+        g->streams[si].subtree = (int)g->subtrees.size();
+        g->subtrees.push_back(st);
+        if ((int)g->passes.size() <= pass) g->passes.resize(pass + 1);
+        g->passes[pass].push_back((int)si);
+    }
+
+    // device: histories + static tables
+    for (auto& s : g->streams) {
+        for (int i = 0; i < 2; i++) {
+            SDRX_HIP(hipMalloc(reinterpret_cast<void**>(&s.hist[i]), TK_HIST * 4));
+            SDRX_HIP(hipMemsetAsync(s.hist[i], 0, TK_HIST * 4, b->stream));
+        }
+    }
+    const size_t b0 = g->subtrees.size() * sizeof(TkSubtree), b1 = g->nodes.size() * sizeof(TkNode), b2 = g->arrays.size() * sizeof(TkArray);
+    if (b0 + b1 + b2 > 0) {
+        SDRX_HIP(hipMalloc(&g->d_static, b0 + b1 + b2 + 64));
+        char* p = static_cast<char*>(g->d_static);
+        g->d_subtrees = reinterpret_cast<TkSubtree*>(p);
+        g->d_nodes = reinterpret_cast<TkNode*>(p + b0);
+        g->d_arrays = reinterpret_cast<TkArray*>(p + b0 + b1);
+        if (b0) SDRX_HIP(hipMemcpy(g->d_subtrees, g->subtrees.data(), b0, hipMemcpyHostToDevice));
+        if (b1) SDRX_HIP(hipMemcpy(g->d_nodes, g->nodes.data(), b1, hipMemcpyHostToDevice));
+        if (b2) SDRX_HIP(hipMemcpy(g->d_arrays, g->arrays.data(), b2, hipMemcpyHostToDevice));
+    }
+    return SDRX_OK;
+}
+
+static int configure_channel(sdrx_chan_bank* b, int c, int32_t req_rate, int32_t req_fc)
+{
+    Channel& ch = b->ch[c];
+    ch.req_rate = req_rate; ch.req_fc = req_fc;
+    ch.n = plan_chain(b->in_rate, req_rate, req_fc, ch.modes, MAX_STAGES, &ch.out_rate, &ch.ofs);
+    ch.passthrough = ch.n == 0;
+    return SDRX_OK;
+}
+
+static int new_group(sdrx_chan_bank* b, const std::vector<int>& chans)
+{
+    if (chans.empty()) return SDRX_OK;
+    Group* g = new (std::nothrow) Group;
+    if (!g) return SDRX_ENOMEM;
+    g->chans = chans;
+    g->index = (int)b->groups.size();
+    int rc = plan_group(b, g);
+    if (rc) { free_group(g); return rc; }
+    for (int c : chans) b->ch[c].group = (int)b->groups.size();
+    b->groups.push_back(g);
+    return SDRX_OK;
+}
+
+// keep `used` bytes when growing a channel queue
+static int grow_keep(sdrx_chan_bank* b, DevBuf& buf, size_t used, size_t need)
+{
+    if (need <= buf.cap) return SDRX_OK;
+    size_t want = buf.cap ? buf.cap : (1 << 16);
+    while (want < need) want *= 2;
+    void* np = nullptr;
+    SDRX_HIP(hipMalloc(&np, want));
+    if (used) SDRX_HIP(hipMemcpyAsync(np, buf.p, used, hipMemcpyDeviceToDevice, b->stream));
+    SDRX_HIP(hipStreamSynchronize(b->stream));
+    if (buf.p) (void)hipFree(buf.p);
+    buf.p = np; buf.cap = want;
+    return SDRX_OK;
+}
+
+static int dyn_slot(sdrx_chan_bank* b, size_t bytes, int* slot)
+{
+    const int s = b->dyn_next; b->dyn_next = (b->dyn_next + 1) % sdrx_chan_bank::RING;
+    if (b->dyn_ev[s]) SDRX_HIP(hipEventSynchronize(b->dyn_ev[s]));
+    else SDRX_HIP(hipEventCreateWithFlags(&b->dyn_ev[s], hipEventDisableTiming));
+    if (bytes > b->dyn_cap[s]) {
+        size_t want = b->dyn_cap[s] ? b->dyn_cap[s] : 4096; while (want < bytes) want *= 2;
+        if (b->h_dyn[s]) (void)hipHostFree(b->h_dyn[s]);
+        if (b->d_dyn[s]) (void)hipFree(b->d_dyn[s]);
+        b->h_dyn[s] = b->d_dyn[s] = nullptr; b->dyn_cap[s] = 0;
+        SDRX_HIP(hipHostMalloc(&b->h_dyn[s], want, hipHostMallocDefault));
+        SDRX_HIP(hipMalloc(&b->d_dyn[s], want));
+        b->dyn_cap[s] = want;
+    }
+    *slot = s;
+    return SDRX_OK;
+}
+
+static int feed_group(sdrx_chan_bank* b, Group* g, const uint32_t* d_in, int64_t n)
+{
+    const int64_t T0 = g->T, T1 = g->T + n;
+    // --- make room in the channel queues and the node-stream buffers
+    for (int c : g->chans) {
+        Channel& ch = b->ch[c];
+        if (ch.group != g->index) continue;                // reconfigured away from this group
+        const int64_t add = (T1 >> ch.n) - (T0 >> ch.n);
+        int rc = grow_keep(b, ch.out, (size_t)ch.avail * 4, (size_t)(ch.avail + add) * 4 + 64); if (rc) return rc;
+    }
+    for (size_t si = 1; si < g->streams.size(); si++) {
+        Stream& s = g->streams[si];
+        const int64_t add = (T1 >> s.depth) - (T0 >> s.depth);
+        int rc = s.mid.reserve((size_t)add * 4 + 64); if (rc) return rc;
+    }
+    // --- dynamic tables: [TkStream x n_streams][TkSink x n_sinks][TkHistJob x n_streams]
+    const size_t ns = g->streams.size(), nk = g->sinks.size();
+    const size_t o_sinks = ns * sizeof(TkStream), o_hist = o_sinks + nk * sizeof(TkSink), total = o_hist + ns * sizeof(TkHistJob);
+    int slot; int rc = dyn_slot(b, total, &slot); if (rc) return rc;
+    char* hp = static_cast<char*>(b->h_dyn[slot]); char* dp = static_cast<char*>(b->d_dyn[slot]);
+    TkStream* hs = reinterpret_cast<TkStream*>(hp);
+    TkSink* hk = reinterpret_cast<TkSink*>(hp + o_sinks);
+    TkHistJob* hh = reinterpret_cast<TkHistJob*>(hp + o_hist);
+
+    std::vector<long> segs(ns, 0);
+    for (size_t si = 0; si < ns; si++) {
+        Stream& s = g->streams[si];
+        TkStream& t = hs[si];
+        t.hist = s.hist[s.cur];
+        t.in = si == 0 ? d_in : static_cast<const uint32_t*>(s.mid.p);
+        t.t_old = T0 >> s.depth; t.t_new = T1 >> s.depth;
+        t.subtree = s.subtree;
+        t.c_first = t.t_old / TK_CHUNK;
+        t.c_last = t.t_new > t.t_old ? (t.t_new - 1) / TK_CHUNK : t.c_first - 1;
+        t.cps = 1;
+        hh[si] = TkHistJob{ s.hist[s.cur], t.in, s.hist[s.cur ^ 1], t.t_new - t.t_old };
+    }
+    for (size_t k = 0; k < nk; k++) {
+        const SinkInfo& si = g->sinks[k];
+        TkSink& t = hk[k];
+        t.shift = 0; t.next = si.next;
+        if (si.kind == 0) {
+            Channel& ch = b->ch[si.ch];
+            t.lo = T0 >> si.depth; t.hi = T1 >> si.depth;
+            t.base = t.lo - ch.avail;
+            t.ptr = static_cast<uint32_t*>(ch.out.p);
+            t.shift = si.depth;
+            if (ch.group != g->index) t.hi = t.lo;         // reconfigured away: still evaluated, not stored
+        } else {
+            Stream& s = g->streams[si.stream];
+            t.lo = T0 >> s.depth; t.hi = T1 >> s.depth; t.base = t.lo;
+            t.ptr = static_cast<uint32_t*>(s.mid.p);
+        }
+    }
+    // chunks per segment, per pass: ~4 workgroups per CU overall, warm-up overhead <= 1/cps
+    for (size_t p = 0; p < g->passes.size(); p++) {
+        long total_chunks = 0;
+        for (int si : g->passes[p]) total_chunks += std::max(0L, hs[si].c_last - hs[si].c_first + 1);
+        long cps = total_chunks / ((long)b->cus * 4);
+        const char* env = getenv("SDRX_CHAN_CPS");
+        if (env && atoi(env) > 0) cps = atoi(env);
+        cps = std::max(1L, std::min(cps, 256L));
+        for (int si : g->passes[p]) {
+            hs[si].cps = (int)cps;
+            segs[si] = (std::max(0L, hs[si].c_last - hs[si].c_first + 1) + cps - 1) / cps;
+        }
+    }
+    SDRX_HIP(hipMemcpyAsync(dp, hp, total, hipMemcpyHostToDevice, b->stream));
+    SDRX_HIP(hipEventRecord(b->dyn_ev[slot], b->stream));
+
+    const TkStream* d_streams = reinterpret_cast<const TkStream*>(dp);
+    const TkSink* d_sinks = reinterpret_cast<const TkSink*>(dp + o_sinks);
+    const TkHistJob* d_hist = reinterpret_cast<const TkHistJob*>(dp + o_hist);
+    const size_t lds_bytes = (size_t)g->max_lds_dw * 4;
+    rc = b->timer.begin(b->stream); if (rc) return rc;
+    for (size_t p = 0; p < g->passes.size(); p++) {
+        // the streams of one pass are contiguous in creation order; launch them as grid.y
+        const std::vector<int>& ps = g->passes[p];
+        if (ps.empty()) continue;
+        long max_segs = 0;
+        for (int si : ps) max_segs = std::max(max_segs, segs[si]);
+        if (max_segs == 0) continue;
+        const int s0 = ps.front(), cnt = (int)ps.size();
+        hipLaunchKernelGGL(tree_kernel, dim3((unsigned)max_segs, (unsigned)cnt), dim3(TK_THREADS), lds_bytes, b->stream,
+                           g->d_subtrees, g->d_nodes, g->d_arrays, d_streams + s0, d_sinks);
+        SDRX_HIP(hipGetLastError());
+        if (p == 0) {
+            snprintf(b->last_name, sizeof b->last_name, "tree_kernel");
+            b->last_grid = (int)(max_segs * cnt); b->last_block = TK_THREADS; b->last_lds = (int)lds_bytes;
+        }
+    }
+    rc = b->timer.end(b->stream); if (rc) return rc;
+    hipLaunchKernelGGL(tree_hist_kernel, dim3(TK_HIST / 256, (unsigned)ns), dim3(256), 0, b->stream, d_hist);
+    SDRX_HIP(hipGetLastError());
+    for (auto& s : g->streams) s.cur ^= 1;
+    for (int c : g->chans) {
+        Channel& ch = b->ch[c];
+        if (ch.group != g->index) continue;
+        const int64_t add = (T1 >> ch.n) - (T0 >> ch.n);
+        ch.last_off = ch.avail; ch.last_n = add; ch.avail += add;
+    }
+    g->T = T1;
+    return SDRX_OK;
+}
+
+static int feed_passthrough(sdrx_chan_bank* b, const uint32_t* d_in, int64_t n)
+{
+    // no stage at all: DownChannelizer::feed hands the input straight to the sink (downchannelizer.cpp:57-60)
+    for (auto& ch : b->ch) {
+        if (!ch.passthrough) continue;
+        int rc = grow_keep(b, ch.out, (size_t)ch.avail * 4, (size_t)(ch.avail + n) * 4 + 64); if (rc) return rc;
+        SDRX_HIP(hipMemcpyAsync(static_cast<uint32_t*>(ch.out.p) + ch.avail, d_in, (size_t)n * 4, hipMemcpyDeviceToDevice, b->stream));
+        ch.last_off = ch.avail; ch.last_n = n; ch.avail += n;
+    }
+    return SDRX_OK;
+}
+
+extern "C" {
+
+int sdrx_chan_plan(int32_t in_rate, int32_t req_rate, int32_t req_fc, uint8_t* modes, int32_t* out_rate, int32_t* residual_ofs)
+{
+    if (!modes || !out_rate || !residual_ofs) { set_error("sdrx_chan_plan: null argument"); return SDRX_EINVAL; }
+    return plan_chain(in_rate, req_rate, req_fc, modes, MAX_STAGES, out_rate, residual_ofs);
+}
+
+int sdrx_chan_bank_create(sdrx_chan_bank_t** out, int device, int32_t in_rate, int32_t n_ch,
+                          const int32_t* req_rate, const int32_t* req_fc)
+{
+    if (!out) { set_error("sdrx_chan_bank_create: null out"); return SDRX_EINVAL; }
+    *out = nullptr;
+    if (n_ch <= 0 || !req_rate || !req_fc || in_rate <= 0) { set_error("sdrx_chan_bank_create: bad argument"); return SDRX_EINVAL; }
+    int rc = check_device(device); if (rc) return rc;
+    SDRX_HIP(hipSetDevice(device));
+    sdrx_chan_bank* b = new (std::nothrow) sdrx_chan_bank;
+    if (!b) return SDRX_ENOMEM;
+    b->device = device; b->in_rate = in_rate; b->cus = device_cu_count(device);
+    hipError_t e = hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete b; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
+    b->stream = b->own_stream;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { sdrx_chan_bank_destroy(b); return hip_fail(e, "hipFuncSetAttribute", __FILE__, __LINE__); }
+    b->ch.resize((size_t)n_ch);
+    std::vector<int> all;
+    for (int c = 0; c < n_ch; c++) {
+        configure_channel(b, c, req_rate[c], req_fc[c]);
+        if (!b->ch[c].passthrough) all.push_back(c);
+    }
+    rc = new_group(b, all);
+    if (rc) { sdrx_chan_bank_destroy(b); return rc; }
+    SDRX_HIP(hipStreamSynchronize(b->stream));
+    *out = b;
+    return SDRX_OK;
+}
+
+int sdrx_chan_bank_destroy(sdrx_chan_bank_t* b)
+{
+    if (!b) return SDRX_OK;
+    (void)hipSetDevice(b->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    for (Group* g : b->groups) free_group(g);
+    for (auto& c : b->ch) c.out.release();
+    b->stage_in.release(); b->scratch.release(); b->timer.release();
+    for (int i = 0; i < sdrx_chan_bank::RING; i++) {
+        if (b->h_dyn[i]) (void)hipHostFree(b->h_dyn[i]);
+        if (b->d_dyn[i]) (void)hipFree(b->d_dyn[i]);
+        if (b->dyn_ev[i]) (void)hipEventDestroy(b->dyn_ev[i]);
+    }
+    if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
+    delete b;
+    return SDRX_OK;
+}
+
+int sdrx_chan_bank_info(const sdrx_chan_bank_t* b, int32_t c, int32_t* n_stages, uint8_t* modes, int32_t* out_rate, int32_t* residual_ofs)
+{
+    if (!b || c < 0 || c >= (int32_t)b->ch.size()) { set_error("sdrx_chan_bank_info: bad channel"); return SDRX_EINVAL; }
+    const Channel& ch = b->ch[(size_t)c];
+    if (n_stages) *n_stages = ch.n;
+    if (modes) memcpy(modes, ch.modes, (size_t)ch.n);
+    if (out_rate) *out_rate = ch.out_rate;
+    if (residual_ofs) *residual_ofs = ch.ofs;
+    return SDRX_OK;
+}
+
+int sdrx_chan_bank_reconfigure(sdrx_chan_bank_t* b, int32_t c, int32_t req_rate, int32_t req_fc)
+{
+    if (!b || c < 0 || c >= (int32_t)b->ch.size()) { set_error("sdrx_chan_bank_reconfigure: bad channel"); return SDRX_EINVAL; }
+    SDRX_HIP(hipSetDevice(b->device));
+    Channel& ch = b->ch[(size_t)c];
+    // the old chain keeps being evaluated inside its group (its prefixes are shared) but stops
+    // storing; the new chain starts from zero history in a group of its own
+    // (freeFilterChain + createFilterChain, downchannelizer.cpp:167-171)
+    ch.group = -1;
+    configure_channel(b, c, req_rate, req_fc);
+    if (ch.passthrough) return SDRX_OK;
+    return new_group(b, std::vector<int>{ c });
+}
+
+int sdrx_chan_bank_reset(sdrx_chan_bank_t* b)
+{
+    if (!b) return SDRX_EINVAL;
+    SDRX_HIP(hipSetDevice(b->device));
+    SDRX_HIP(hipStreamSynchronize(b->stream));
+    for (Group* g : b->groups) free_group(g);
+    b->groups.clear();
+    std::vector<int> all;
+    for (size_t c = 0; c < b->ch.size(); c++) {
+        b->ch[c].avail = 0; b->ch[c].last_n = 0; b->ch[c].group = -1;
+        if (!b->ch[c].passthrough) all.push_back((int)c);
+    }
+    return new_group(b, all);
+}
+
+int sdrx_chan_bank_feed_dev(sdrx_chan_bank_t* b, const int16_t* d_iq, int64_t n_cplx)
+{
+    if (!b || n_cplx < 0 || (n_cplx > 0 && !d_iq)) { set_error("sdrx_chan_bank_feed_dev: bad argument"); return SDRX_EINVAL; }
+    if (reinterpret_cast<uintptr_t>(d_iq) & 3u) { set_error("sdrx_chan_bank_feed_dev: d_iq must be 4-byte aligned"); return SDRX_EINVAL; }
+    if (n_cplx == 0) return SDRX_OK;
+    SDRX_HIP(hipSetDevice(b->device));
+    const uint32_t* in = reinterpret_cast<const uint32_t*>(d_iq);
+    int rc = feed_passthrough(b, in, n_cplx); if (rc) return rc;
+    for (Group* g : b->groups) { rc = feed_group(b, g, in, n_cplx); if (rc) return rc; }
+    return SDRX_OK;
+}
+
+int sdrx_chan_bank_feed(sdrx_chan_bank_t* b, const int16_t* iq, int64_t n_cplx)
+{
+    if (!b || n_cplx < 0 || (n_cplx > 0 && !iq)) { set_error("sdrx_chan_bank_feed: bad argument"); return SDRX_EINVAL; }
+    if (n_cplx == 0) return SDRX_OK;
+    SDRX_HIP(hipSetDevice(b->device));
+    SDRX_HIP(hipStreamSynchronize(b->stream));            // staging buffer may still be read by the previous feed
+    int rc = b->stage_in.reserve((size_t)n_cplx * 4); if (rc) return rc;
+    SDRX_HIP(hipMemcpyAsync(b->stage_in.p, iq, (size_t)n_cplx * 4, hipMemcpyHostToDevice, b->stream));
+    return sdrx_chan_bank_feed_dev(b, static_cast<const int16_t*>(b->stage_in.p), n_cplx);
+}
+
+int64_t sdrx_chan_bank_available(sdrx_chan_bank_t* b, int32_t c)
+{
+    if (!b || c < 0 || c >= (int32_t)b->ch.size()) return SDRX_EINVAL;
+    return b->ch[(size_t)c].avail;
+}
+
+int64_t sdrx_chan_bank_read(sdrx_chan_bank_t* b, int32_t c, int16_t* out_iq, int64_t cap)
+{
+    if (!b || c < 0 || c >= (int32_t)b->ch.size() || cap < 0 || (cap > 0 && !out_iq)) { set_error("sdrx_chan_bank_read: bad argument"); return SDRX_EINVAL; }
+    if (hipSetDevice(b->device) != hipSuccess) return SDRX_EHIP;
+    Channel& ch = b->ch[(size_t)c];
+    const int64_t n = std::min(cap, ch.avail);
+    if (n == 0) return 0;
+    hipError_t e = hipMemcpyAsync(out_iq, ch.out.p, (size_t)n * 4, hipMemcpyDeviceToHost, b->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(read)", __FILE__, __LINE__);
+    const int64_t rest = ch.avail - n;
+    if (rest > 0) {                                        // partial read: compact the queue
+        int rc = b->scratch.reserve((size_t)rest * 4); if (rc) return rc;
+        e = hipMemcpyAsync(b->scratch.p, static_cast<uint32_t*>(ch.out.p) + n, (size_t)rest * 4, hipMemcpyDeviceToDevice, b->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ch.out.p, b->scratch.p, (size_t)rest * 4, hipMemcpyDeviceToDevice, b->stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(compact)", __FILE__, __LINE__);
+    }
+    e = hipStreamSynchronize(b->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
+    ch.avail = rest; ch.last_off = 0; ch.last_n = 0;
+    return n;
+}
+
+int sdrx_chan_bank_last_dev(sdrx_chan_bank_t* b, int32_t c, const int16_t** d_out_iq, int64_t* n_cplx)
+{
+    if (!b || c < 0 || c >= (int32_t)b->ch.size() || !d_out_iq || !n_cplx) { set_error("sdrx_chan_bank_last_dev: bad argument"); return SDRX_EINVAL; }
+    Channel& ch = b->ch[(size_t)c];
+    *d_out_iq = reinterpret_cast<const int16_t*>(static_cast<uint32_t*>(ch.out.p) + ch.last_off);
+    *n_cplx = ch.last_n;
+    return SDRX_OK;
+}
+
+int sdrx_chan_bank_sync(sdrx_chan_bank_t* b)
+{
+    if (!b) return SDRX_EINVAL;
+    SDRX_HIP(hipSetDevice(b->device));
+    SDRX_HIP(hipStreamSynchronize(b->stream));
+    return SDRX_OK;
+}
+
+int sdrx_chan_bank_set_stream(sdrx_chan_bank_t* b, void* hip_stream)
+{
+    if (!b) return SDRX_EINVAL;
+    SDRX_HIP(hipSetDevice(b->device));
+    SDRX_HIP(hipStreamSynchronize(b->stream));
+    b->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : b->own_stream;
+    return SDRX_OK;
+}
+
+int sdrx_chan_bank_set_timing(sdrx_chan_bank_t* b, int enabled)
+{
+    if (!b) return SDRX_EINVAL;
+    b->timer.enabled = enabled != 0;
+    return SDRX_OK;
+}
+
+int sdrx_chan_bank_get_timing(sdrx_chan_bank_t* b, double* total_ms, int64_t* feeds, int reset)
+{
+    if (!b) return SDRX_EINVAL;
+    SDRX_HIP(hipSetDevice(b->device));
+    int rc = b->timer.collect(b->stream); if (rc) return rc;
+    if (total_ms) *total_ms = b->timer.total_ms;
+    if (feeds) *feeds = b->timer.count;
+    if (reset) { b->timer.total_ms = 0; b->timer.count = 0; }
+    return SDRX_OK;
+}
+
+int sdrx_chan_bank_last_launch(const sdrx_chan_bank_t* b, char* kernel_name, int name_cap, int* grid, int* block, int* lds_bytes)
+{
+    if (!b) return SDRX_EINVAL;
+    if (kernel_name && name_cap > 0) snprintf(kernel_name, (size_t)name_cap, "%s", b->last_name);
+    if (grid) *grid = b->last_grid;
+    if (block) *block = b->last_block;
+    if (lds_bytes) *lds_bytes = b->last_lds;
+    return SDRX_OK;
+}
+
+} // extern "C"

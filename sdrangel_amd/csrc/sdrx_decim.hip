@@ -1,0 +1,308 @@
+// libsdrx.so: sdrx_decim_* -- drop-in for Decimators<qint32,qint16,16,InputBits>
+// (sdrbase/dsp/decimators.h:279-341).  Host logic + kernel dispatch; kernels in decim_kernel.hpp.
+#include "sdrx_common.hpp"
+#include "decim_kernel.hpp"
+#include <cstring>
+#include <cstdlib>
+#include <new>
+
+namespace sdrx {
+
+// decimate1 (decimators.h:344-355): (int16)(x << pre1), elementwise
+__global__ void decim1_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, long n, int pre)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const uint32_t v = in[i];
+        const int re = (int)(int16_t)(v & 0xffffu), im = (int)(int16_t)(v >> 16);
+        out[i] = pack_iq((int)((uint32_t)re << pre), (int)((uint32_t)im << pre));
+    }
+}
+
+// new history = last DC_CHUNK samples of (old history ++ consumed input)
+__global__ void hist_update_kernel(const uint32_t* __restrict__ old_hist, const uint32_t* __restrict__ in,
+                                   uint32_t* __restrict__ new_hist, long n_in)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= DC_CHUNK) return;
+    const long src = (long)i + n_in - DC_CHUNK;
+    new_hist[i] = src >= 0 ? in[src] : old_hist[i + n_in];
+}
+
+typedef void (*chain_fn)(const uint4*, const uint4*, uint32_t*, long, int, int, int);
+
+struct ChainEntry { chain_fn fn; const char* name; int lds; };
+
+template<int L, int FC, int PRE> static ChainEntry entry()
+{
+    static char name[64];
+    snprintf(name, sizeof name, "decim_chain_kernel<%d,%d,%d>", L, FC, PRE);
+    return ChainEntry{ &decim_chain_kernel<L, FC, PRE>, name, dc_lds_dwords(L) * 4 };
+}
+
+// decimation_shifts<16,InputBits> (decimators.h:25-185)
+static void shifts(int bits, int log2, int* pre, int* post)
+{
+    static const int pre12[7] = { 4, 3, 2, 1, 0, 0, 0 }, post12[7] = { 0, 0, 0, 0, 0, 1, 2 };
+    static const int pre8[7]  = { 8, 7, 6, 5, 4, 3, 2 };
+    if (bits == 12) { *pre = pre12[log2]; *post = post12[log2]; }
+    else if (bits == 8) { *pre = pre8[log2]; *post = 0; }
+    else { *pre = 0; *post = log2; }
+}
+
+template<int L, int FC> static bool pick_pre(int pre, ChainEntry* e)
+{
+    // the only `pre` values decimation_shifts<16,{8,12,16}> produce for this L
+    constexpr int p12[7] = { 4, 3, 2, 1, 0, 0, 0 }, p8[7] = { 8, 7, 6, 5, 4, 3, 2 };
+    if (pre == 0)      { *e = entry<L, FC, 0>(); return true; }
+    if (pre == p12[L]) { *e = entry<L, FC, p12[L]>(); return true; }
+    if (pre == p8[L])  { *e = entry<L, FC, p8[L]>(); return true; }
+    return false;
+}
+template<int L> static bool pick_fc(int fc, int pre, ChainEntry* e)
+{
+    switch (fc) {
+    case 0: return pick_pre<L, 0>(pre, e);
+    case 1: return pick_pre<L, 1>(pre, e);
+    default: return pick_pre<L, 2>(pre, e);
+    }
+}
+static bool pick(int L, int fc, int pre, ChainEntry* e)
+{
+    switch (L) {
+    case 1: return pick_fc<1>(fc, pre, e);
+    case 2: return pick_fc<2>(fc, pre, e);
+    case 3: return pick_fc<3>(fc, pre, e);
+    case 4: return pick_fc<4>(fc, pre, e);
+    case 5: return pick_fc<5>(fc, pre, e);
+    case 6: return pick_fc<6>(fc, pre, e);
+    }
+    return false;
+}
+
+} // namespace sdrx
+
+using namespace sdrx;
+
+struct sdrx_decim {
+    int device = 0, log2 = 0, fcpos = 2, bits = 12, pre = 0, post = 0, group = 2;
+    int cus = 256;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    uint32_t* d_hist[2] = { nullptr, nullptr };
+    int cur = 0;
+    DevBuf d_in, d_out;
+    ChainEntry k{ nullptr, "", 0 };
+    char last_name[96] = "";
+    int last_grid = 0, last_block = 0, last_lds = 0;
+    EventTimer timer;
+};
+
+static int group_int16(int log2, int fcpos)
+{
+    // `pos +=` strides of decimateK_* (decimators.h:348, 467, 545, 687, 833, 1099, 1605, 2614, 2664, 2742, 2862, 3080, 3492)
+    if (log2 == 0) return 2;
+    if (log2 <= 2) return 4 << log2;
+    return fcpos == SDRX_FC_CEN ? (2 << log2) : (4 << log2);
+}
+
+// choose chunks-per-segment: minimise (cps + 1 warm-up) * waves of segments over `slots` resident workgroups
+static int choose_cps(long n_chunks, int slots)
+{
+    const char* env = getenv("SDRX_DECIM_CPS");
+    if (env && atoi(env) > 0) return atoi(env);
+    long best = 1; double best_cost = 1e300;
+    for (long cps = 1; cps <= n_chunks && cps <= 4096; cps = cps < 16 ? cps + 1 : cps + cps / 8) {
+        const long segs = (n_chunks + cps - 1) / cps;
+        const long rounds = (segs + slots - 1) / slots;
+        const double cost = (double)(cps + 1) * (double)rounds;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = cps; }
+    }
+    return (int)best;
+}
+
+static int launch(sdrx_decim* h, const int16_t* d_iq, long n_cplx, int16_t* d_out)
+{
+    // n_cplx: whole groups only (caller truncated)
+    if (n_cplx <= 0) return SDRX_OK;
+    if (h->log2 == 0) {
+        const int block = 256;
+        long grid = (n_cplx + block - 1) / block; if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(decim1_kernel, dim3((unsigned)grid), dim3(block), 0, h->stream,
+                           reinterpret_cast<const uint32_t*>(d_iq), reinterpret_cast<uint32_t*>(d_out), n_cplx, h->pre);
+        SDRX_HIP(hipGetLastError());
+        snprintf(h->last_name, sizeof h->last_name, "decim1_kernel");
+        h->last_grid = (int)grid; h->last_block = block; h->last_lds = 0;
+        return SDRX_OK;
+    }
+    const long n_chunks = (n_cplx + DC_CHUNK - 1) / DC_CHUNK;
+    if (n_chunks > 0x7fffffffL) { set_error("input too long for one call"); return SDRX_EINVAL; }
+    const int cps = choose_cps(n_chunks, h->cus * 3);
+    const long segs = (n_chunks + cps - 1) / cps;
+    int trc = h->timer.begin(h->stream); if (trc) return trc;
+    hipLaunchKernelGGL(h->k.fn, dim3((unsigned)segs), dim3(DC_THREADS), 0, h->stream,
+                       reinterpret_cast<const uint4*>(h->d_hist[h->cur]), reinterpret_cast<const uint4*>(d_iq),
+                       reinterpret_cast<uint32_t*>(d_out), n_cplx, (int)n_chunks, cps, h->post);
+    SDRX_HIP(hipGetLastError());
+    trc = h->timer.end(h->stream); if (trc) return trc;
+    hipLaunchKernelGGL(hist_update_kernel, dim3(DC_CHUNK / 256), dim3(256), 0, h->stream,
+                       h->d_hist[h->cur], reinterpret_cast<const uint32_t*>(d_iq), h->d_hist[h->cur ^ 1], n_cplx);
+    SDRX_HIP(hipGetLastError());
+    h->cur ^= 1;
+    snprintf(h->last_name, sizeof h->last_name, "%s", h->k.name);
+    h->last_grid = (int)segs; h->last_block = DC_THREADS; h->last_lds = h->k.lds;
+    return SDRX_OK;
+}
+
+extern "C" {
+
+int sdrx_decim_group_int16(int log2_decim, int fcpos) { return group_int16(log2_decim, fcpos); }
+
+int sdrx_decim_create(sdrx_decim_t** out, int device, int log2_decim, int fcpos, int input_bits)
+{
+    if (!out) { set_error("sdrx_decim_create: null out"); return SDRX_EINVAL; }
+    *out = nullptr;
+    if (log2_decim < 0 || log2_decim > 6 || fcpos < 0 || fcpos > 2 ||
+        (input_bits != 8 && input_bits != 12 && input_bits != 16)) {
+        set_error("sdrx_decim_create: log2 0..6, fcpos 0..2, input_bits 8|12|16");
+        return SDRX_EINVAL;
+    }
+    int rc = check_device(device);
+    if (rc) return rc;
+    SDRX_HIP(hipSetDevice(device));
+    sdrx_decim* h = new (std::nothrow) sdrx_decim;
+    if (!h) return SDRX_ENOMEM;
+    h->device = device; h->log2 = log2_decim; h->fcpos = fcpos; h->bits = input_bits;
+    shifts(input_bits, log2_decim, &h->pre, &h->post);
+    h->group = group_int16(log2_decim, fcpos);
+    h->cus = device_cu_count(device);
+    if (log2_decim > 0 && !pick(log2_decim, fcpos, h->pre, &h->k)) {
+        delete h; set_error("sdrx_decim_create: no kernel for this configuration"); return SDRX_EINVAL;
+    }
+    hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
+    h->stream = h->own_stream;
+    for (int i = 0; i < 2; i++) {
+        e = hipMalloc(reinterpret_cast<void**>(&h->d_hist[i]), DC_CHUNK * 4);
+        if (e != hipSuccess) { sdrx_decim_destroy(h); return hip_fail(e, "hipMalloc(hist)", __FILE__, __LINE__); }
+    }
+    *out = h;
+    return sdrx_decim_reset(h);
+}
+
+int sdrx_decim_destroy(sdrx_decim_t* h)
+{
+    if (!h) return SDRX_OK;
+    (void)hipSetDevice(h->device);
+    if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); }
+    for (int i = 0; i < 2; i++) if (h->d_hist[i]) (void)hipFree(h->d_hist[i]);
+    h->d_in.release(); h->d_out.release(); h->timer.release();
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return SDRX_OK;
+}
+
+int sdrx_decim_reset(sdrx_decim_t* h)
+{
+    if (!h) return SDRX_EINVAL;
+    SDRX_HIP(hipSetDevice(h->device));
+    SDRX_HIP(hipMemsetAsync(h->d_hist[h->cur], 0, DC_CHUNK * 4, h->stream));
+    return SDRX_OK;
+}
+
+int sdrx_decim_set_stream(sdrx_decim_t* h, void* hip_stream)
+{
+    if (!h) return SDRX_EINVAL;
+    SDRX_HIP(hipSetDevice(h->device));
+    SDRX_HIP(hipStreamSynchronize(h->stream));            // order pending work before switching
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return SDRX_OK;
+}
+
+int sdrx_decim_sync(sdrx_decim_t* h)
+{
+    if (!h) return SDRX_EINVAL;
+    SDRX_HIP(hipSetDevice(h->device));
+    SDRX_HIP(hipStreamSynchronize(h->stream));
+    return SDRX_OK;
+}
+
+int sdrx_decim_process_dev(sdrx_decim_t* h, const int16_t* d_iq, int64_t n_int16, int16_t* d_out_iq, int64_t* n_out_cplx)
+{
+    if (!h || n_int16 < 0 || (n_int16 > 0 && (!d_iq || !d_out_iq))) { set_error("sdrx_decim_process_dev: bad argument"); return SDRX_EINVAL; }
+    if ((reinterpret_cast<uintptr_t>(d_iq) & 15u) || (reinterpret_cast<uintptr_t>(d_out_iq) & 3u)) {
+        set_error("sdrx_decim_process_dev: d_iq must be 16-byte aligned"); return SDRX_EINVAL;
+    }
+    SDRX_HIP(hipSetDevice(h->device));
+    const int64_t groups = n_int16 / h->group;            // trailing partial group dropped (decimators.h:3492)
+    const int64_t n_cplx = groups * (h->group / 2);
+    if (n_out_cplx) *n_out_cplx = n_cplx >> h->log2;
+    return launch(h, d_iq, (long)n_cplx, d_out_iq);
+}
+
+int sdrx_decim_process(sdrx_decim_t* h, const int16_t* iq, int32_t n_int16, int16_t* out_iq, int32_t* n_out_cplx)
+{
+    if (!h || n_int16 < 0 || (n_int16 > 0 && (!iq || !out_iq))) { set_error("sdrx_decim_process: bad argument"); return SDRX_EINVAL; }
+    SDRX_HIP(hipSetDevice(h->device));
+    const int64_t groups = n_int16 / h->group;
+    const int64_t n_cplx = groups * (h->group / 2);
+    const int64_t n_out = n_cplx >> h->log2;
+    if (n_out_cplx) *n_out_cplx = (int32_t)n_out;
+    if (n_cplx == 0) return SDRX_OK;
+    int rc = h->d_in.reserve((size_t)n_cplx * 4); if (rc) return rc;
+    rc = h->d_out.reserve((size_t)n_out * 4); if (rc) return rc;
+    SDRX_HIP(hipMemcpyAsync(h->d_in.p, iq, (size_t)n_cplx * 4, hipMemcpyHostToDevice, h->stream));
+    rc = launch(h, static_cast<const int16_t*>(h->d_in.p), (long)n_cplx, static_cast<int16_t*>(h->d_out.p));
+    if (rc) return rc;
+    SDRX_HIP(hipMemcpyAsync(out_iq, h->d_out.p, (size_t)n_out * 4, hipMemcpyDeviceToHost, h->stream));
+    SDRX_HIP(hipStreamSynchronize(h->stream));
+    return SDRX_OK;
+}
+
+int64_t sdrx_decim_state_bytes(const sdrx_decim_t*) { return (int64_t)DC_CHUNK * 4; }
+
+int sdrx_decim_get_state(sdrx_decim_t* h, void* host_buf)
+{
+    if (!h || !host_buf) return SDRX_EINVAL;
+    SDRX_HIP(hipSetDevice(h->device));
+    SDRX_HIP(hipMemcpyAsync(host_buf, h->d_hist[h->cur], DC_CHUNK * 4, hipMemcpyDeviceToHost, h->stream));
+    SDRX_HIP(hipStreamSynchronize(h->stream));
+    return SDRX_OK;
+}
+
+int sdrx_decim_set_state(sdrx_decim_t* h, const void* host_buf)
+{
+    if (!h || !host_buf) return SDRX_EINVAL;
+    SDRX_HIP(hipSetDevice(h->device));
+    SDRX_HIP(hipMemcpyAsync(h->d_hist[h->cur], host_buf, DC_CHUNK * 4, hipMemcpyHostToDevice, h->stream));
+    SDRX_HIP(hipStreamSynchronize(h->stream));
+    return SDRX_OK;
+}
+
+int sdrx_decim_set_timing(sdrx_decim_t* h, int enabled)
+{
+    if (!h) return SDRX_EINVAL;
+    h->timer.enabled = enabled != 0;
+    return SDRX_OK;
+}
+
+int sdrx_decim_get_timing(sdrx_decim_t* h, double* total_ms, int64_t* launches, int reset)
+{
+    if (!h) return SDRX_EINVAL;
+    SDRX_HIP(hipSetDevice(h->device));
+    int rc = h->timer.collect(h->stream); if (rc) return rc;
+    if (total_ms) *total_ms = h->timer.total_ms;
+    if (launches) *launches = h->timer.count;
+    if (reset) { h->timer.total_ms = 0; h->timer.count = 0; }
+    return SDRX_OK;
+}
+
+int sdrx_decim_last_launch(const sdrx_decim_t* h, char* kernel_name, int name_cap, int* grid, int* block, int* lds_bytes)
+{
+    if (!h) return SDRX_EINVAL;
+    if (kernel_name && name_cap > 0) snprintf(kernel_name, (size_t)name_cap, "%s", h->last_name);
+    if (grid) *grid = h->last_grid;
+    if (block) *block = h->last_block;
+    if (lds_bytes) *lds_bytes = h->last_lds;
+    return SDRX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,243 @@
+// DownChannelizer bank as a tree of half-band stages -- ONE generic gfx950 kernel, launched once
+// per "pass" (reference: DownChannelizer::feed, sdrbase/dsp/downchannelizer.cpp:50-91, and
+// IntHalfbandFilterEO<qint32,qint32,48>::workDecimate{Center,LowerHalf,UpperHalf}(Sample*),
+// inthalfbandfiltereo.h:37-63,158-206,357-405 with doFIR(Sample*) :792-830).
+//
+// The N channels' stage strings form a trie; every distinct prefix (= node) is ONE order-48
+// half-band stage evaluated ONCE.  The host planner (sdrx_chan.hip) cuts the trie into passes of
+// at most 6 levels: a pass reads a stream (the raw input, or a node stream a previous pass wrote
+// to global memory), walks it in chunks of 4096 samples with all stage histories carried in LDS,
+// and writes channel outputs and/or deeper node streams.  One warm-up chunk (4096 >= 46*(2^6-1))
+// in front of every time segment makes the carried LDS state exact.
+//
+// Everything here is int16 by construction (Sample storage), so every stage runs on packed int16
+// polyphase arms with v_dot2c_i32_i16 (stage_pk16_r8).  The int16-wrapping negation of the
+// lower/upper-half rotations ((FixReal) -sample->imag(), :164) matters on the odd arm
+// (-(-32768) stays -32768): producers therefore store an extra, explicitly wrap-negated
+// "alternating sign" copy of the odd arm for L/U children.  On the even arm (centre tap only) the
+// sign is folded into the tap: a wrap there changes acc by 2^27, i.e. y by exactly 2^16, which
+// the int16 store discards.
+#pragma once
+#include "hb_common.hpp"
+
+namespace sdrx {
+
+constexpr int TK_CHUNK = 4096;
+constexpr int TK_THREADS = 256;
+constexpr int TK_MAX_LEVELS = 6;
+constexpr int TK_HIST = 2 * TK_CHUNK;        // samples of stream history kept between feeds
+
+struct TkNode {                 // 64 B, one half-band stage
+    int oddI, oddQ;             // LDS dword offsets: odd arm it reads (parent's plain or alt copy)
+    int cenI, cenQ;             // even-arm arrays feeding the I / Q accumulators (swapped for L/U)
+    uint32_t cIe, cIo, cQe, cQo;// packed centre taps for even / odd output index
+    int outE_I, outE_Q;         // own output arms (-1: none): even
+    int outO_I, outO_Q;         //   odd, plain (for a centre child)
+    int outA_I, outA_Q;         //   odd, alternating wrap-negated (for lower/upper children)
+    int sink, pad;              // head of this node's sink list (index into the sink table), -1: none
+};
+
+struct TkLevel { int node_base, n_nodes, jobs_log2, nout; };   // nout = outputs per node per chunk
+
+struct TkSubtree {
+    int n_levels;
+    int n_nodes;                // all levels
+    int node_base;              // first node (global index) -- levels index relative to the table
+    int n_arrays, array_base;   // carry list
+    int lds_dwords;             // arms + node table copy
+    int node_tab;               // LDS dword offset of the node table copy
+    int rootE_I, rootE_Q, rootO_I, rootO_Q, rootA_I, rootA_Q;   // root arms (-1: none)
+    TkLevel lv[TK_MAX_LEVELS];
+};
+
+struct TkArray { int off, len; };            // LDS dword offset / length of one polyphase array
+
+struct TkStream {               // per feed, per input stream of a pass
+    const uint32_t* hist;       // TK_HIST samples: absolute positions [t_old - TK_HIST, t_old)
+    const uint32_t* in;         // new samples: absolute positions [t_old, t_new)
+    long t_old, t_new;
+    long c_first, c_last;       // absolute chunk range to (re)compute
+    int cps;                    // chunks per segment
+    int subtree;
+};
+
+struct TkSink {                 // where a node's outputs go in global memory
+    uint32_t* ptr;              // element 0 <-> absolute output index `base`
+    long base, lo, hi;          // store only absolute output indices in [lo, hi)
+    int shift;                  // 0: raw node stream; n > 0: channel end, value / 2^n (toward zero)
+    int next;                   // next sink of the same node, -1: end of list
+};
+
+__device__ __forceinline__ int div_pow2_trunc(int v, int n)
+{
+    // s.m_real /= (1 << n)  (downchannelizer.cpp:80): C division of the promoted int16
+    return (v + ((v >> 31) & ((1 << n) - 1))) >> n;
+}
+
+__global__ __launch_bounds__(TK_THREADS, 2)
+void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restrict__ nodes,
+                 const TkArray* __restrict__ arrays, const TkStream* __restrict__ streams,
+                 const TkSink* __restrict__ sinks)
+{
+    constexpr int C = TK_CHUNK, NT = TK_THREADS, LPT = C / 4 / NT;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+
+    const TkStream sp = streams[blockIdx.y];
+    const long first = sp.c_first + (long)blockIdx.x * sp.cps;
+    if (first > sp.c_last) return;
+    long last = first + sp.cps - 1; if (last > sp.c_last) last = sp.c_last;
+    const TkSubtree& st = subtrees[sp.subtree];
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < st.lds_dwords; i += NT) lds[i] = 0;
+    __syncthreads();
+    {   // node table -> LDS (16 dwords per node)
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(nodes + st.node_base);
+        for (int i = tid; i < st.n_nodes * 16; i += NT) lds[st.node_tab + i] = src[i];
+    }
+
+    uint4 pre[LPT];
+    auto fetch = [&](long chunk) {
+#pragma unroll
+        for (int j = 0; j < LPT; j++) {
+            const long p0 = chunk * C + 4 * (j * NT + tid);       // absolute position of the 4 samples
+            if (p0 >= sp.t_old && p0 + 4 <= sp.t_new) {
+                pre[j] = *reinterpret_cast<const uint4*>(sp.in + (p0 - sp.t_old));
+            } else {
+                uint32_t v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const long p = p0 + e;
+                    v[e] = p < sp.t_old ? sp.hist[p - (sp.t_old - TK_HIST)] : (p < sp.t_new ? sp.in[p - sp.t_old] : 0u);
+                }
+                pre[j] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    };
+    fetch(first - 1);
+    __syncthreads();
+
+    for (long chunk = first - 1; chunk <= last; ++chunk) {
+        // ---- stream samples -> root arms
+#pragma unroll
+        for (int j = 0; j < LPT; j++) {
+            const int q = HIST / 2 + j * NT + tid;
+            const uint4 v = pre[j];
+            const uint32_t oI = __builtin_amdgcn_perm(v.w, v.y, 0x05040100u);
+            const uint32_t oQ = __builtin_amdgcn_perm(v.w, v.y, 0x07060302u);
+            lds[st.rootE_I + q] = __builtin_amdgcn_perm(v.z, v.x, 0x05040100u);
+            lds[st.rootE_Q + q] = __builtin_amdgcn_perm(v.z, v.x, 0x07060302u);
+            if (st.rootO_I >= 0) { lds[st.rootO_I + q] = oI; lds[st.rootO_Q + q] = oQ; }
+            if (st.rootA_I >= 0) {
+                // odd-arm index m even (low half) -> wrap-negated, m odd -> as is
+                lds[st.rootA_I + q] = ((0u - oI) & 0xffffu) | (oI & 0xffff0000u);
+                lds[st.rootA_Q + q] = ((0u - oQ) & 0xffffu) | (oQ & 0xffff0000u);
+            }
+        }
+        if (chunk < last) fetch(chunk + 1);
+        __syncthreads();
+
+        const bool live = chunk >= first;
+        for (int l = 0; l < st.n_levels; l++) {
+            const TkLevel lv = st.lv[l];
+            const int njobs = lv.n_nodes << lv.jobs_log2;
+            for (int j = tid; j < njobs; j += NT) {
+                const int ni = lv.node_base + (j >> lv.jobs_log2);
+                const int t = j & ((1 << lv.jobs_log2) - 1);
+                const uint4* nt = reinterpret_cast<const uint4*>(lds + st.node_tab + ni * 16);
+                const uint4 n0 = nt[0], n1 = nt[1], n2 = nt[2], n3 = nt[3];
+                // --- the stage: 8 outputs, packed int16 arms, centre taps from the node
+                int yI[8], yQ[8];
+                {
+                    const uint32_t* oI = lds + (int)n0.x, *oQ = lds + (int)n0.y;
+                    const uint32_t* cI = lds + (int)n0.z, *cQ = lds + (int)n0.w;
+                    uint32_t wI[20], wQ[20];
+                    const uint4* pI = reinterpret_cast<const uint4*>(oI + 4 * t);
+                    const uint4* pQ = reinterpret_cast<const uint4*>(oQ + 4 * t);
+#pragma unroll
+                    for (int q = 0; q < 5; q++) {
+                        uint4 a = pI[q], b = pQ[q];
+                        wI[4*q] = a.x; wI[4*q+1] = a.y; wI[4*q+2] = a.z; wI[4*q+3] = a.w;
+                        wQ[4*q] = b.x; wQ[4*q+1] = b.y; wQ[4*q+2] = b.z; wQ[4*q+3] = b.w;
+                    }
+                    constexpr int EB = (32 - (hb_pairs<48>() - 1) - 1) / 2;      // 10
+                    uint32_t vI[5], vQ[5];
+#pragma unroll
+                    for (int q = 0; q < 5; q++) { vI[q] = cI[4 * t + EB + q]; vQ[q] = cQ[4 * t + EB + q]; }
+                    static_for<0, 8>([&](auto rc) {
+                        constexpr int r = decltype(rc)::value;
+                        int aI = 0, aQ = 0;
+                        static_for<0, 20>([&](auto dc) {
+                            constexpr int d = decltype(dc)::value;
+                            constexpr uint32_t cf = pk_coef<48, MODE_CEN>(r, d);
+                            if constexpr (cf != 0) { aI = dot2(wI[d], cf, aI); aQ = dot2(wQ[d], cf, aQ); }
+                        });
+                        constexpr int dd = (r + 1) >> 1;
+                        aI = dot2(vI[dd], (r & 1) ? n1.y : n1.x, aI);
+                        aQ = dot2(vQ[dd], (r & 1) ? n1.w : n1.z, aQ);
+                        yI[r] = (int)(int16_t)(aI >> (HB_SHIFT - 1));               // Sample::setReal (:828)
+                        yQ[r] = (int)(int16_t)(aQ >> (HB_SHIFT - 1));
+                    });
+                }
+                // --- own arms for the children
+                if ((int)n2.x >= 0) {
+                    const int p = HIST / 2 + 2 * t;
+                    const uint32_t e0I = pack_iq(yI[0], yI[2]), e1I = pack_iq(yI[4], yI[6]);
+                    const uint32_t e0Q = pack_iq(yQ[0], yQ[2]), e1Q = pack_iq(yQ[4], yQ[6]);
+                    *reinterpret_cast<uint2*>(lds + (int)n2.x + p) = make_uint2(e0I, e1I);
+                    *reinterpret_cast<uint2*>(lds + (int)n2.y + p) = make_uint2(e0Q, e1Q);
+                    const uint32_t o0I = pack_iq(yI[1], yI[3]), o1I = pack_iq(yI[5], yI[7]);
+                    const uint32_t o0Q = pack_iq(yQ[1], yQ[3]), o1Q = pack_iq(yQ[5], yQ[7]);
+                    if ((int)n2.z >= 0) {
+                        *reinterpret_cast<uint2*>(lds + (int)n2.z + p) = make_uint2(o0I, o1I);
+                        *reinterpret_cast<uint2*>(lds + (int)n2.w + p) = make_uint2(o0Q, o1Q);
+                    }
+                    if ((int)n3.x >= 0) {
+                        auto alt = [](uint32_t v) { return ((0u - v) & 0xffffu) | (v & 0xffff0000u); };
+                        *reinterpret_cast<uint2*>(lds + (int)n3.x + p) = make_uint2(alt(o0I), alt(o1I));
+                        *reinterpret_cast<uint2*>(lds + (int)n3.y + p) = make_uint2(alt(o0Q), alt(o1Q));
+                    }
+                }
+                // --- global sinks (channel ends and node streams for the next pass)
+                if (live) {
+                    const long abs0 = chunk * lv.nout + 8 * t;
+                    for (int si = (int)n3.z; si >= 0; ) {
+                        const TkSink sk = sinks[si];
+#pragma unroll
+                        for (int r = 0; r < 8; r++) {
+                            const long a = abs0 + r;
+                            if (a >= sk.lo && a < sk.hi) {
+                                const int re = sk.shift ? div_pow2_trunc(yI[r], sk.shift) : yI[r];
+                                const int im = sk.shift ? div_pow2_trunc(yQ[r], sk.shift) : yQ[r];
+                                sk.ptr[a - sk.base] = pack_iq(re, im);
+                            }
+                        }
+                        si = sk.next;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- carry: last 32 int16 (16 dwords) of every array become the next chunk's history
+        for (int i = tid; i < st.n_arrays * 16; i += NT) {
+            const TkArray a = arrays[st.array_base + (i >> 4)];
+            lds[a.off + (i & 15)] = lds[a.off + a.len - 16 + (i & 15)];
+        }
+        __syncthreads();
+    }
+}
+
+// new history = last TK_HIST samples of (old history ++ new samples); one block row per stream
+struct TkHistJob { const uint32_t* old_hist; const uint32_t* in; uint32_t* new_hist; long n_new; };
+
+__global__ void tree_hist_kernel(const TkHistJob* __restrict__ jobs)
+{
+    const TkHistJob jb = jobs[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= TK_HIST) return;
+    const long src = (long)i + jb.n_new - TK_HIST;
+    jb.new_hist[i] = src >= 0 ? jb.in[src] : jb.old_hist[i + jb.n_new];
+}
+
+} // namespace sdrx
