@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the sdrx hot path on MI355X, one JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload decim64|chan32]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE pass of the hot path over one batch of synthetic int16 I/Q that is already resident
+in HBM: `sdrx_decim_process_dev` (decimate64_cen, Decimators<qint32,qint16,16,12>, BASELINE.json
+configs[1]) over a batch of 256 Mi complex samples (1 GiB) of one stream.  With N > 1 every rank owns one
+GPU and one independent stream (streams shard, no collective on the data path);
+per-GPU work is fixed, so scaling is "weak" and `value` is the sum over ranks.
+
+roofline : dominant kernel's ALGORITHMIC bytes (4 B read + 4/64 B written per input sample =
+           4.0625 B/sample) / its average duration, measured with HIP events on the
+           launch stream inside the library (sdrx_decim_get_timing), against 8 TB/s HBM3E.
+cpu_baseline : the reference's own decimate64_cen (oracle/_ref/libsdrref.so, built from
+           /root/reference in the build container; kind "reference") or, if that .so did not travel,
+           the oracle port (oracle/libsdro_fast.so; kind "port"), one independent stream per thread
+           on the host cores of this box, bounded sample.  The oracle is only the checker/baseline:
+           nothing on the measured GPU path touches it.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E datasheet (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def cpu_baseline(sample_cplx: int, reps: int, log2: int = 6):
+    """Reference (or port) decimate64_cen, one stream per thread, on the host cores."""
+    import numpy as np
+    from tests import oracle_py as orc
+    n_thr = max(1, min(os.cpu_count() or 1, 16))
+    x = orc.synth_iq(sample_cplx, seed=1234, amp=2047)
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libsdrref.so")
+    kind = None
+    if os.path.exists(ref_so):
+        try:
+            L = C.CDLL(ref_so)
+            L.ref_decim_new.restype = C.c_void_p; L.ref_decim_new.argtypes = [C.c_int]
+            L.ref_decim_process.restype = C.c_int
+            L.ref_decim_process.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int32, C.c_void_p]
+            mk = lambda: L.ref_decim_new(12)
+            run = lambda h, buf, out: L.ref_decim_process(h, log2, 2, buf.ctypes.data, buf.size, out.ctypes.data)
+            kind = "reference"
+        except OSError:
+            kind = None
+    if kind is None:
+        fast = os.path.join(ROOT, "oracle", "libsdro_fast.so")
+        if not os.path.exists(fast):
+            import subprocess
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libsdro_fast.so"])
+        L = orc.lib(fast=True)
+        mk = lambda: L.sdro_decim_new(log2, 2, 12)
+        run = lambda h, buf, out: L.sdro_decim_process(h, buf.ctypes.data, buf.size, out.ctypes.data)
+        kind = "port"
+
+    def timed(n_threads):
+        hs = [mk() for _ in range(n_threads)]
+        bufs = [x.copy() for _ in range(n_threads)]
+        outs = [np.empty(sample_cplx // (1 << log2) * 2 + 64, np.int16) for _ in range(n_threads)]
+        for i in range(n_threads):
+            run(hs[i], bufs[i][: 2 * 65536], outs[i])          # touch / warm
+        def work(i):
+            for _ in range(reps):
+                run(hs[i], bufs[i], outs[i])
+        th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+        t0 = time.perf_counter()
+        for t in th: t.start()
+        for t in th: t.join()
+        dt = time.perf_counter() - t0
+        return n_threads * reps * sample_cplx / dt / 1e6
+
+    one = timed(1)
+    allc = timed(n_thr) if n_thr > 1 else one
+    return {"value": round(allc, 2), "unit": "MS/s", "cores": n_thr, "kind": kind,
+            "single_thread_MSps": round(one, 2),
+            "sample": f"decimate64_cen <16,12> on {sample_cplx} synthetic int16 I/Q samples x {reps} passes per thread, "
+                      f"one independent stream per thread ({n_thr} threads); single_thread_MSps = 1 thread, as sdrangelbench runs it"}
+
+
+def load_traffic(kernel: str, batch: int):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/*traffic*.json), or None."""
+    import glob
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+        try:
+            d = json.load(open(p))
+        except Exception:
+            continue
+        for e in d.get("kernels", []):
+            if e.get("kernel", "").startswith(kernel.split("<")[0]) and e.get("batch_cplx") == batch and kernel in e.get("kernel", ""):
+                best = e.get("hbm_bytes_per_launch")
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="decim64", choices=["decim64", "chan32"])
+    ap.add_argument("--batch", type=int, default=256 * 1024 * 1024, help="complex samples per step per GPU (1 GiB of int16 I/Q)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import sdrangel_amd as sa
+    sa.lib()                                    # before torch: one HIP runtime (see sdrangel_amd/__init__.py)
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+    n_gpus = world
+
+    B = args.batch
+    g = torch.Generator(device=dev); g.manual_seed(5489 + rank)
+    # sdrbench-shaped data: uniform 12-bit noise, I/Q interleaved (mainbench.cpp:76-79) + an in-band tone
+    x = torch.randint(-2048, 2048, (2 * B,), generator=g, device=dev, dtype=torch.int32)
+    t = torch.arange(B, device=dev, dtype=torch.float32)
+    x[0::2] += (600 * torch.cos(2 * torch.pi * 0.0011 * t)).to(torch.int32)
+    x[1::2] += (600 * torch.sin(2 * torch.pi * 0.0011 * t)).to(torch.int32)
+    x = x.clamp_(-32768, 32767).to(torch.int16)
+    del t
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    if args.workload == "decim64":
+        h = sa.Decimators(6, sa.FC_CEN, 12, device=dev.index)
+        out = torch.empty(2 * (B >> 6) + 64, dtype=torch.int16, device=dev)
+        h.set_stream(stream)
+        step = lambda: h.decimate_dev(x.data_ptr(), 2 * B, out.data_ptr())
+        bytes_per_sample = 4.0 + 4.0 / 64
+        workload = f"cfg2: decimate64_cen Decimators<qint32,qint16,16,12>, one stream per GPU, {B} complex int16 samples per step, device-resident"
+    else:
+        k = torch.arange(32, dtype=torch.float64)
+        fcs = (-15_000_000 + k * (30_000_000 / 31) + 137 * k).to(torch.int64).tolist()
+        h = sa.ChannelizerBank(61_440_000, [48000] * 32, fcs, device=dev.index)
+        h.set_stream(stream)
+        def step():
+            h.feed_dev(x.data_ptr(), B)
+            for c in range(32):                 # consumer side: drop the queued outputs (host bookkeeping only)
+                h.skip(c)
+        bytes_per_sample = 4.0 + 32 * 4.0 / 1024
+        workload = f"cfg3: DownChannelizer bank, 32 channels (48 kS/s each) from one 61.44 MS/s-shaped stream per GPU, {B} samples per step"
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    h.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    k_ms, k_n = h.get_timing()
+    h.set_timing(False)
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.barrier()
+    elapsed = float(el.item())
+
+    if rank == 0:
+        value = n_gpus * args.steps * B / elapsed / 1e6
+        kern_ms = k_ms / max(k_n, 1)
+        achieved = bytes_per_sample * B / (kern_ms * 1e-3) / 1e9
+        ll = h.last_launch()
+        line = {
+            "metric": "MS/s complex int16 IQ through decim-64 + DownChannelizer, 1/2/4/8 GPU; % HBM roofline",
+            "value": round(value, 1), "unit": "MS/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": workload, "streams": n_gpus, "parallelism": f"{n_gpus} independent stream(s), one per GPU, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": load_traffic(ll["kernel"], B),
+                         "kernel": ll["kernel"], "kernel_ms": round(kern_ms, 4), "launches": k_n,
+                         "algorithmic_bytes_per_sample": bytes_per_sample,
+                         "grid": ll["grid"], "block": ll["block"], "lds_bytes": ll["lds_bytes"]},
+        }
+        if n_gpus == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(8 * 1024 * 1024, 16)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -122,6 +122,8 @@ int64_t sdrx_chan_bank_available(sdrx_chan_bank_t* h, int32_t ch);
 /* == the m_sampleBuffer handed to m_sampleSink->feed (downchannelizer.cpp:87): copies up to cap
  * complex samples of channel ch to host memory and removes them; returns the count (<0: error) */
 int64_t sdrx_chan_bank_read(sdrx_chan_bank_t* h, int32_t ch, int16_t* out_iq, int64_t cap);
+/* readCommit-style: discard up to n queued samples of channel ch without copying (n < 0: all) */
+int64_t sdrx_chan_bank_skip(sdrx_chan_bank_t* h, int32_t ch, int64_t n);
 /* device-side view of what the last feed produced for channel ch (valid until the next feed) */
 int sdrx_chan_bank_last_dev(sdrx_chan_bank_t* h, int32_t ch, const int16_t** d_out_iq, int64_t* n_cplx);
 int sdrx_chan_bank_sync(sdrx_chan_bank_t* h);

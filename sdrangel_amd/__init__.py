@@ -81,6 +81,7 @@ def lib() -> C.CDLL:
         "sdrx_chan_bank_feed_dev": (C.c_int, [vp, vp, i64]),
         "sdrx_chan_bank_available": (i64, [vp, i32]),
         "sdrx_chan_bank_read": (i64, [vp, i32, vp, i64]),
+        "sdrx_chan_bank_skip": (i64, [vp, i32, i64]),
         "sdrx_chan_bank_last_dev": (C.c_int, [vp, i32, pp, C.POINTER(i64)]),
         "sdrx_chan_bank_sync": (C.c_int, [vp]),
         "sdrx_chan_bank_set_stream": (C.c_int, [vp, vp]),
@@ -252,6 +253,9 @@ class ChannelizerBank:
         if n < 0:
             raise SdrxError(f"sdrx_chan_bank_read rc={n}: {lib().sdrx_last_error().decode()}")
         return out[: 2 * n]
+
+    def skip(self, ch: int, n: int = -1) -> int:
+        return lib().sdrx_chan_bank_skip(self._h, ch, n)
 
     def sync(self):
         _check(lib().sdrx_chan_bank_sync(self._h), "sdrx_chan_bank_sync")

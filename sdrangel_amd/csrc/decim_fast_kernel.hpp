@@ -1,0 +1,309 @@
+// FAST path of the Decimators chain: one WAVE = one private pipeline, no workgroup barrier.
+//
+// Each 64-lane workgroup (a single wavefront) owns `spw` consecutive sub-chunks of 1024 input
+// samples and walks them in order through all L half-band stages, every stage's history carried
+// in its own 11 KB LDS slice; 4 warm-up sub-chunks (4096 >= 62*(2^L-1) samples) in front of the
+// segment make that state exact.  With no s_barrier anywhere, the 12-14 resident waves of a CU
+// interleave freely on the SIMDs, and every stage keeps all 64 lanes busy:
+//     stage 1,2,3 : packed-int16 arms, v_dot2c_i32_i16, 8 / 4 / 2 outputs per lane (I and Q)
+//     stage 4     : int32 arms, lane = (output pair, component)
+//     stage 5     : int32 arms, lane = (output pair, component, half of the taps)  + DPP add
+//     stage 6     : int32 arms, lane = (output pair, component, quarter of the taps) + DPP adds
+//
+// Exactness: stage 1 is exact for ANY int16 input.  Stages 2 and 3 read their inputs as int16;
+// that is exact iff every stage-1 and stage-2 output fits int16, which the kernel CHECKS (running
+// min/max).  For 8/12-bit device data honouring its contract the worst-case bound (3.49x per
+// stage) guarantees it; otherwise the wave raises the overflow flag of every 4096-sample chunk
+// from the failing sub-chunk to the end of its segment and the EXACT kernel (decim_kernel.hpp,
+// int32 arms throughout, launched right behind on the same stream) recomputes exactly those
+// chunks.  With both outputs < 2^15 the static bounds also make v_mad_i32_i24 exact in stages 4-6.
+#pragma once
+#include "hb_common.hpp"
+#include "decim_kernel.hpp"
+
+namespace sdrx {
+
+constexpr int DF_SUB = 1024;          // input samples per sub-chunk (one wave iteration)
+constexpr int DF_WARM = 4;            // warm-up sub-chunks
+constexpr int DF_CHUNK = 4096;        // flag granularity == DC_CHUNK of the EXACT kernel
+
+// generic packed-int16 stage, R outputs (I and Q) per lane; see stage_pk16_r8 for the derivation
+template<int ORDER, int MODE, int SHL, int R>
+__device__ __forceinline__ void stage_pk16(const uint32_t* __restrict__ oI, const uint32_t* __restrict__ oQ,
+                                           const uint32_t* __restrict__ eI, const uint32_t* __restrict__ eQ,
+                                           int t, int (&yI)[R], int (&yQ)[R])
+{
+    constexpr int P = hb_pairs<ORDER>();
+    constexpr int CD = P - 1;
+    constexpr int NW = (R + 32) / 2;                 // window dwords: int16 i holds o[k0-32+i]
+    constexpr int EB = (32 - CD - 1) / 2, NE = R / 2 + 1;
+    uint32_t wI[NW], wQ[NW], vI[NE], vQ[NE];
+    const int b = (R / 2) * t;
+    if constexpr (R == 8) {
+#pragma unroll
+        for (int q = 0; q < NW / 4; q++) {
+            uint4 a = reinterpret_cast<const uint4*>(oI + b)[q], c = reinterpret_cast<const uint4*>(oQ + b)[q];
+            wI[4*q] = a.x; wI[4*q+1] = a.y; wI[4*q+2] = a.z; wI[4*q+3] = a.w;
+            wQ[4*q] = c.x; wQ[4*q+1] = c.y; wQ[4*q+2] = c.z; wQ[4*q+3] = c.w;
+        }
+    } else if constexpr (R == 4) {
+#pragma unroll
+        for (int q = 0; q < NW / 2; q++) {
+            uint2 a = reinterpret_cast<const uint2*>(oI + b)[q], c = reinterpret_cast<const uint2*>(oQ + b)[q];
+            wI[2*q] = a.x; wI[2*q+1] = a.y; wQ[2*q] = c.x; wQ[2*q+1] = c.y;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NW; q++) { wI[q] = oI[b + q]; wQ[q] = oQ[b + q]; }
+    }
+#pragma unroll
+    for (int q = 0; q < NE; q++) { vI[q] = eI[b + EB + q]; vQ[q] = eQ[b + EB + q]; }
+
+    static_for<0, R>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        int aI = 0, aQ = 0;
+        static_for<0, NW>([&](auto dc) {
+            constexpr int d = decltype(dc)::value;
+            constexpr uint32_t cf = pk_coef<ORDER, MODE>(r, d);
+            if constexpr (cf != 0) { aI = dot2(wI[d], cf, aI); aQ = dot2(wQ[d], cf, aQ); }
+        });
+        constexpr int dd = (r + 1) >> 1, hf = (r + 1) & 1;
+        constexpr uint32_t cp = hf ? pk16(0, 2048) : pk16(2048, 0);
+        constexpr uint32_t cn = hf ? pk16(0, -2048) : pk16(-2048, 0);
+        if constexpr (MODE == MODE_CEN) {
+            aI = dot2(vI[dd], cp, aI); aQ = dot2(vQ[dd], cp, aQ);
+        } else {
+            constexpr bool neg_first = ((r & 1) == 1) == (MODE == MODE_INF);
+            aI = dot2(vQ[dd], neg_first ? cn : cp, aI);
+            aQ = dot2(vI[dd], neg_first ? cp : cn, aQ);
+        }
+        yI[r] = (int)((uint32_t)aI << SHL) >> (HB_SHIFT - 1);
+        yQ[r] = (int)((uint32_t)aQ << SHL) >> (HB_SHIFT - 1);
+    });
+}
+
+// R outputs -> next stage's PACKED int16 arms (dword 16 = first of the chunk)
+template<int R>
+__device__ __forceinline__ void put_pk16(uint32_t* __restrict__ oI, uint32_t* __restrict__ oQ,
+                                         uint32_t* __restrict__ eI, uint32_t* __restrict__ eQ,
+                                         int t, const int (&yI)[R], const int (&yQ)[R])
+{
+    static_assert(R == 8 || R == 4, "packed output needs at least two samples per arm");
+    if constexpr (R == 8) {
+        const int p = HIST / 2 + 2 * t;
+        *reinterpret_cast<uint2*>(eI + p) = make_uint2(pack_iq(yI[0], yI[2]), pack_iq(yI[4], yI[6]));
+        *reinterpret_cast<uint2*>(oI + p) = make_uint2(pack_iq(yI[1], yI[3]), pack_iq(yI[5], yI[7]));
+        *reinterpret_cast<uint2*>(eQ + p) = make_uint2(pack_iq(yQ[0], yQ[2]), pack_iq(yQ[4], yQ[6]));
+        *reinterpret_cast<uint2*>(oQ + p) = make_uint2(pack_iq(yQ[1], yQ[3]), pack_iq(yQ[5], yQ[7]));
+    } else {
+        const int p = HIST / 2 + t;
+        eI[p] = pack_iq(yI[0], yI[2]); oI[p] = pack_iq(yI[1], yI[3]);
+        eQ[p] = pack_iq(yQ[0], yQ[2]); oQ[p] = pack_iq(yQ[1], yQ[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// int32-arm stage for the low-rate tail: lane = (output pair p, component, tap slice h).
+// Two outputs k = 2p, 2p+1 of ONE component per lane, taps [h*16/SPLIT, (h+1)*16/SPLIT) of the 16
+// coefficient pairs, partial sums combined over the SPLIT neighbouring lanes.  Every lane of a
+// (p, component) group ends up holding the finished outputs.
+// ---------------------------------------------------------------------------------------------
+template<int MODE, int SPLIT, bool M24>
+__device__ __forceinline__ void stage_i32_split(const int* __restrict__ oI, const int* __restrict__ oQ,
+                                                const int* __restrict__ eI, const int* __restrict__ eQ,
+                                                int lane, int (&y)[2], int& p_out, int& comp_out)
+{
+    constexpr int P = 16, TAPS = 32, CD = 15, PP = P / SPLIT;
+    const int h = lane % SPLIT, comp = (lane / SPLIT) & 1, p = lane / (2 * SPLIT);
+    const int* o = comp ? oQ : oI;
+    // a[j] = o[k - i], b[j] = o[k - 31 + i] for i = h*PP + ii; indices relative to entry 32 + 2p
+    const int abase = HIST + 2 * p - (h * PP + PP - 1);          // o index of a for (r = 0, ii = PP-1)
+    const int bbase = HIST + 2 * p - (TAPS - 1) + h * PP;         // o index of b for (r = 0, ii = 0)
+    int a[PP + 1], b[PP + 1];
+#pragma unroll
+    for (int q = 0; q < PP + 1; q++) { a[q] = o[abase + q]; b[q] = o[bbase + q]; }
+    int acc[2] = { 0, 0 };
+    static_for<0, 2>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        static_for<0, PP>([&](auto ic) {
+            constexpr int ii = decltype(ic)::value;
+            // coefficient index i = h*PP + ii is lane dependent: fetch c[i] from a tiny per-lane table
+            const int av = a[PP - 1 - ii + r], bv = b[ii + r];
+            int cf;
+            if constexpr (SPLIT == 1) cf = hb_c<64>(ii);
+            else if constexpr (SPLIT == 2) cf = h ? hb_c<64>(PP + ii) : hb_c<64>(ii);
+            else cf = h == 0 ? hb_c<64>(ii) : h == 1 ? hb_c<64>(PP + ii) : h == 2 ? hb_c<64>(2 * PP + ii) : hb_c<64>(3 * PP + ii);
+            if constexpr (MODE == MODE_CEN) {
+                acc[r] = mac<M24>(acc[r], (int)((uint32_t)av + (uint32_t)bv), cf);
+            } else {
+                // s(m) = (-1)^(m+1), m = k - i, k = 2p + r, i = h*PP + ii with PP even: parity of r - ii
+                constexpr int sg = (((r - ii) & 1) == 0) ? -1 : 1;
+                acc[r] = mac<M24>(acc[r], (int)((uint32_t)av - (uint32_t)bv), sg * cf);
+            }
+        });
+    });
+    if constexpr (SPLIT >= 2) { acc[0] += __shfl_xor(acc[0], 1); acc[1] += __shfl_xor(acc[1], 1); }
+    if constexpr (SPLIT >= 4) { acc[0] += __shfl_xor(acc[0], 2); acc[1] += __shfl_xor(acc[1], 2); }
+    // centre tap e[k - 15]: own component for centre mode, the other one (signed) for inf/sup
+    const int* e = (MODE == MODE_CEN) ? (comp ? eQ : eI) : (comp ? eI : eQ);
+    const int cbase = HIST + 2 * p - CD;
+    static_for<0, 2>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        const uint32_t c = (uint32_t)e[cbase + r] << (HB_SHIFT - 1);
+        uint32_t u;
+        if constexpr (MODE == MODE_CEN) u = (uint32_t)acc[r] + c;
+        else {
+            // I: -eQ when neg_first else +eQ;  Q: +eI when neg_first else -eI
+            constexpr bool neg_first = ((r & 1) == 1) == (MODE == MODE_INF);
+            const bool sub = neg_first != (comp != 0);
+            u = sub ? (uint32_t)acc[r] - c : (uint32_t)acc[r] + c;
+        }
+        y[r] = (int)u >> (HB_SHIFT - 1);
+    });
+    p_out = p; comp_out = comp;
+}
+
+// LDS layout of one wave (dwords)
+__host__ __device__ constexpr bool df_in16(int s) { return s <= 3; }          // stage s reads packed int16 arms
+__host__ __device__ constexpr int df_arr(int s)
+{
+    return df_in16(s) ? (HIST / 2 + (DF_SUB >> (s + 1))) : (HIST + (DF_SUB >> s));
+}
+__host__ __device__ constexpr int df_off(int s) { int o = 0; for (int u = 1; u < s; u++) o += 4 * df_arr(u); return o; }
+__host__ __device__ constexpr int df_lds_dwords(int L) { return df_off(L + 1); }
+
+template<int L, int FC, int PRE>
+__global__ __launch_bounds__(64)
+void decim_fast_kernel(const uint4* __restrict__ hist,     // DF_CHUNK samples: tail of the previous call
+                       const uint4* __restrict__ in, uint32_t* __restrict__ out,
+                       uint32_t* __restrict__ ovf_flags,   // one per DF_CHUNK-sample chunk of this call
+                       long n_in, int n_sub, int spw, int post)
+{
+    constexpr int S = DF_SUB, LPT = S / 4 / 64;            // 4 uint4 per lane per sub-chunk
+    __shared__ __attribute__((aligned(16))) uint32_t lds[df_lds_dwords(L)];
+    const int lane = threadIdx.x;
+    const long first = (long)blockIdx.x * spw;
+    if (first >= n_sub) return;
+    long last = first + spw; if (last > n_sub) last = n_sub;
+    const long n_in4 = n_in >> 2, n_out = n_in >> L;
+
+    for (int i = lane; i < df_lds_dwords(L); i += 64) lds[i] = 0;
+
+    uint4 pre[LPT];
+    auto fetch = [&](long sub) {
+#pragma unroll
+        for (int j = 0; j < LPT; j++) {
+            const long g = sub * (S / 4) + j * 64 + lane;         // uint4 index; sub < 0: history
+            if (g < 0) pre[j] = hist[g + DF_CHUNK / 4];
+            else pre[j] = g < n_in4 ? in[g] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    fetch(first - DF_WARM);
+    bool bad = false;
+    int vmin = 0, vmax = 0;                                    // running range of the int16-stored outputs
+    __syncthreads();
+
+    for (long sub = first - DF_WARM; sub < last; ++sub) {
+        {
+            uint32_t* oI = lds + df_off(1), *oQ = oI + df_arr(1), *eI = oQ + df_arr(1), *eQ = eI + df_arr(1);
+#pragma unroll
+            for (int j = 0; j < LPT; j++) {
+                const int q = HIST / 2 + j * 64 + lane;
+                const uint4 v = pre[j];
+                eI[q] = __builtin_amdgcn_perm(v.z, v.x, 0x05040100u);
+                eQ[q] = __builtin_amdgcn_perm(v.z, v.x, 0x07060302u);
+                oI[q] = __builtin_amdgcn_perm(v.w, v.y, 0x05040100u);
+                oQ[q] = __builtin_amdgcn_perm(v.w, v.y, 0x07060302u);
+            }
+        }
+        if (sub + 1 < last) fetch(sub + 1);
+        __syncthreads();                                       // single-wave workgroup: a fence, no s_barrier
+
+        const bool live = sub >= first;
+        static_for<1, L + 1>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr int MODE = dc_mode(L, FC, s);
+            constexpr int NOUT = S >> s;
+            const uint32_t* iI = lds + df_off(s), *iQ = iI + df_arr(s), *jI = iQ + df_arr(s), *jQ = jI + df_arr(s);   // oI,oQ,eI,eQ
+            uint32_t* nI = lds + df_off(s + 1);                // next stage: oI, oQ, eI, eQ
+            if constexpr (s <= 3) {
+                constexpr int R = 16 >> s;                     // 8, 4, 2
+                int yI[R], yQ[R];
+                stage_pk16<64, MODE, (s == 1 ? PRE : 0), R>(iI, iQ, jI, jQ, lane, yI, yQ);
+                if constexpr (s < L) {
+                    if constexpr (s + 1 <= 3) {
+                        // these outputs are re-read as int16: track their range
+#pragma unroll
+                        for (int r = 0; r < R; r += 2) {
+                            vmax = max(vmax, max(max(yI[r], yI[r + 1]), max(yQ[r], yQ[r + 1])));
+                            vmin = min(vmin, min(min(yI[r], yI[r + 1]), min(yQ[r], yQ[r + 1])));
+                        }
+                        put_pk16<R>(nI, nI + df_arr(s + 1), nI + 2 * df_arr(s + 1), nI + 3 * df_arr(s + 1), lane, yI, yQ);
+                    } else {
+                        int* d = reinterpret_cast<int*>(nI);
+                        put_i32<R>(d, d + df_arr(s + 1), d + 2 * df_arr(s + 1), d + 3 * df_arr(s + 1), lane, yI, yQ);
+                    }
+                } else if (live) {
+                    const long base = sub * NOUT + (long)R * lane;
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+                        if (base + r < n_out) out[base + r] = pack_iq(yI[r] >> post, yQ[r] >> post);
+                }
+            } else {
+                constexpr int SPLIT = s == 4 ? 1 : s == 5 ? 2 : 4;
+                int y[2], p, comp;
+                stage_i32_split<MODE, SPLIT, true>(reinterpret_cast<const int*>(iI), reinterpret_cast<const int*>(iQ),
+                                                   reinterpret_cast<const int*>(jI), reinterpret_cast<const int*>(jQ),
+                                                   lane, y, p, comp);
+                if constexpr (s < L) {
+                    int* d = reinterpret_cast<int*>(nI);       // oI, oQ, eI, eQ of the next stage
+                    int* od = d + (comp ? df_arr(s + 1) : 0);
+                    int* ed = d + (comp ? 3 * df_arr(s + 1) : 2 * df_arr(s + 1));
+                    ed[HIST + p] = y[0]; od[HIST + p] = y[1];
+                } else {
+                    // partner component sits SPLIT lanes up; lanes with comp == 0 and slice 0 store
+                    const int q0 = __shfl_down(y[0], SPLIT), q1 = __shfl_down(y[1], SPLIT);
+                    if (live && comp == 0 && (lane % SPLIT) == 0) {
+                        const long base = sub * NOUT + 2 * p;
+                        if (base < n_out)     out[base]     = pack_iq(y[0] >> post, q0 >> post);
+                        if (base + 1 < n_out) out[base + 1] = pack_iq(y[1] >> post, q1 >> post);
+                    }
+                }
+            }
+            __syncthreads();
+        });
+
+        // overflow bookkeeping (wave-uniform): any int16-stored output out of range so far?
+        if constexpr (L >= 2) {
+            const bool mine = vmax > 32767 || vmin < -32768;
+            if (!bad && __any(mine)) bad = true;
+        }
+        if (live && lane == 0 && ((sub + 1) % (DF_CHUNK / S) == 0 || sub + 1 == last))
+            ovf_flags[sub / (DF_CHUNK / S)] = bad ? 1u : 0u;
+
+        // carry: the last HD dwords of every array become the next sub-chunk's history
+        static_for<1, L + 1>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr int HD = df_in16(s) ? HIST / 2 : HIST;
+            constexpr int ND = df_arr(s) - HD;
+            uint32_t* a = lds + df_off(s);
+            // 4 arrays x HD dwords; read everything first (the regions overlap when ND < HD)
+            constexpr int TOT = 4 * HD, PER = (TOT + 63) / 64;
+            uint32_t tmp[PER];
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const int i = q * 64 + lane;
+                tmp[q] = i < TOT ? a[(i / HD) * df_arr(s) + ND + (i % HD)] : 0u;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const int i = q * 64 + lane;
+                if (i < TOT) a[(i / HD) * df_arr(s) + (i % HD)] = tmp[q];
+            }
+        });
+        __syncthreads();
+    }
+}
+
+} // namespace sdrx

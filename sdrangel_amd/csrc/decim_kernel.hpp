@@ -64,6 +64,7 @@ __global__ __launch_bounds__(DC_THREADS, 3)
 void decim_chain_kernel(const uint4* __restrict__ hist,   // DC_CHUNK samples: tail of the previous call
                         const uint4* __restrict__ in,     // n_in samples (16 B aligned)
                         uint32_t* __restrict__ out,       // n_in >> L packed Samples
+                        const uint32_t* __restrict__ flags, // per chunk: recompute? (nullptr: all) -- set by the FAST kernel
                         long n_in, int n_chunks, int cps, int post)
 {
     constexpr int C = DC_CHUNK, NT = DC_THREADS;
@@ -74,6 +75,11 @@ void decim_chain_kernel(const uint4* __restrict__ hist,   // DC_CHUNK samples: t
     const long first = (long)blockIdx.x * cps;
     if (first >= n_chunks) return;
     long last = first + cps; if (last > n_chunks) last = n_chunks;
+    if (flags) {                                          // fallback run: only segments the FAST kernel flagged
+        bool any = false;
+        for (long c = first; c < last; ++c) any = any || flags[c] != 0;
+        if (!any) return;
+    }
     const long n_in4 = n_in >> 2;                         // n_in is a multiple of 4 (group sizes are)
     const long n_out = n_in >> L;
 

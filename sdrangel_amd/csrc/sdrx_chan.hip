@@ -612,6 +612,22 @@ int64_t sdrx_chan_bank_read(sdrx_chan_bank_t* b, int32_t c, int16_t* out_iq, int
     return n;
 }
 
+int64_t sdrx_chan_bank_skip(sdrx_chan_bank_t* b, int32_t c, int64_t n)
+{
+    if (!b || c < 0 || c >= (int32_t)b->ch.size()) { set_error("sdrx_chan_bank_skip: bad argument"); return SDRX_EINVAL; }
+    Channel& ch = b->ch[(size_t)c];
+    if (n < 0 || n >= ch.avail) { const int64_t k = ch.avail; ch.avail = 0; ch.last_off = 0; ch.last_n = 0; return k; }
+    if (n == 0) return 0;
+    if (hipSetDevice(b->device) != hipSuccess) return SDRX_EHIP;
+    const int64_t rest = ch.avail - n;
+    int rc = b->scratch.reserve((size_t)rest * 4); if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(b->scratch.p, static_cast<uint32_t*>(ch.out.p) + n, (size_t)rest * 4, hipMemcpyDeviceToDevice, b->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ch.out.p, b->scratch.p, (size_t)rest * 4, hipMemcpyDeviceToDevice, b->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(skip)", __FILE__, __LINE__);
+    ch.avail = rest; ch.last_off = 0; ch.last_n = 0;
+    return n;
+}
+
 int sdrx_chan_bank_last_dev(sdrx_chan_bank_t* b, int32_t c, const int16_t** d_out_iq, int64_t* n_cplx)
 {
     if (!b || c < 0 || c >= (int32_t)b->ch.size() || !d_out_iq || !n_cplx) { set_error("sdrx_chan_bank_last_dev: bad argument"); return SDRX_EINVAL; }

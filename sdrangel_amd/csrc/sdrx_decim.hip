@@ -2,6 +2,7 @@
 // (sdrbase/dsp/decimators.h:279-341).  Host logic + kernel dispatch; kernels in decim_kernel.hpp.
 #include "sdrx_common.hpp"
 #include "decim_kernel.hpp"
+#include "decim_fast_kernel.hpp"
 #include <cstring>
 #include <cstdlib>
 #include <new>
@@ -28,15 +29,18 @@ __global__ void hist_update_kernel(const uint32_t* __restrict__ old_hist, const 
     new_hist[i] = src >= 0 ? in[src] : old_hist[i + n_in];
 }
 
-typedef void (*chain_fn)(const uint4*, const uint4*, uint32_t*, long, int, int, int);
+typedef void (*chain_fn)(const uint4*, const uint4*, uint32_t*, const uint32_t*, long, int, int, int);
+typedef void (*fast_fn)(const uint4*, const uint4*, uint32_t*, uint32_t*, long, int, int, int);
 
-struct ChainEntry { chain_fn fn; const char* name; int lds; };
+struct ChainEntry { chain_fn fn; fast_fn fast; const char* name; const char* fast_name; int lds; int fast_lds; };
 
 template<int L, int FC, int PRE> static ChainEntry entry()
 {
-    static char name[64];
+    static char name[64], fname[64];
     snprintf(name, sizeof name, "decim_chain_kernel<%d,%d,%d>", L, FC, PRE);
-    return ChainEntry{ &decim_chain_kernel<L, FC, PRE>, name, dc_lds_dwords(L) * 4 };
+    snprintf(fname, sizeof fname, "decim_fast_kernel<%d,%d,%d>", L, FC, PRE);
+    return ChainEntry{ &decim_chain_kernel<L, FC, PRE>, &decim_fast_kernel<L, FC, PRE>, name, fname,
+                       dc_lds_dwords(L) * 4, df_lds_dwords(L) * 4 };
 }
 
 // decimation_shifts<16,InputBits> (decimators.h:25-185)
@@ -89,8 +93,9 @@ struct sdrx_decim {
     hipStream_t own_stream = nullptr, stream = nullptr;
     uint32_t* d_hist[2] = { nullptr, nullptr };
     int cur = 0;
-    DevBuf d_in, d_out;
-    ChainEntry k{ nullptr, "", 0 };
+    DevBuf d_in, d_out, d_flags;
+    int path = 0;                 // 0 auto (FAST + flagged EXACT), 1 exact only, 2 fast only (debug: no fallback)
+    ChainEntry k{ nullptr, nullptr, "", "", 0, 0 };
     char last_name[96] = "";
     int last_grid = 0, last_block = 0, last_lds = 0;
     EventTimer timer;
@@ -134,21 +139,51 @@ static int launch(sdrx_decim* h, const int16_t* d_iq, long n_cplx, int16_t* d_ou
         return SDRX_OK;
     }
     const long n_chunks = (n_cplx + DC_CHUNK - 1) / DC_CHUNK;
-    if (n_chunks > 0x7fffffffL) { set_error("input too long for one call"); return SDRX_EINVAL; }
-    const int cps = choose_cps(n_chunks, h->cus * 3);
-    const long segs = (n_chunks + cps - 1) / cps;
+    if (n_chunks > 0x7fffffffL / 4) { set_error("input too long for one call"); return SDRX_EINVAL; }
+    const uint4* hist = reinterpret_cast<const uint4*>(h->d_hist[h->cur]);
+    const uint4* in4 = reinterpret_cast<const uint4*>(d_iq);
+    uint32_t* out = reinterpret_cast<uint32_t*>(d_out);
+    uint32_t* flags = nullptr;
     int trc = h->timer.begin(h->stream); if (trc) return trc;
-    hipLaunchKernelGGL(h->k.fn, dim3((unsigned)segs), dim3(DC_THREADS), 0, h->stream,
-                       reinterpret_cast<const uint4*>(h->d_hist[h->cur]), reinterpret_cast<const uint4*>(d_iq),
-                       reinterpret_cast<uint32_t*>(d_out), n_cplx, (int)n_chunks, cps, h->post);
-    SDRX_HIP(hipGetLastError());
+    if (h->path != 1) {
+        // FAST: one wave per segment of `spw` sub-chunks (multiple of 4 = one flag chunk), 4 warm-up
+        trc = h->d_flags.reserve((size_t)n_chunks * 4); if (trc) return trc;
+        flags = static_cast<uint32_t*>(h->d_flags.p);
+        const long n_sub = (n_cplx + DF_SUB - 1) / DF_SUB;
+        // segment length: 32 sub-chunks (12.5 % warm-up) measured best once that still gives >= 8 waves
+        // per CU (sweep in profiles/r01_decim_sweep.txt); shorter inputs trade warm-up against fill
+        const long slots = (long)h->cus * 8;
+        long spw = 32; double best = 1e300;
+        const char* env = getenv("SDRX_DECIM_SPW");
+        if (env && atoi(env) >= 4) spw = (atoi(env) / 4) * 4;
+        else if (n_sub < 32 * slots) for (long c = 4; c <= 32; c += 4) {
+            const long segs = (n_sub + c - 1) / c, rounds = (segs + slots - 1) / slots;
+            const double cost = (double)(c + DF_WARM) * (double)rounds;
+            if (cost < best - 1e-9) { best = cost; spw = c; }
+        }
+        const long segs = (n_sub + spw - 1) / spw;
+        hipLaunchKernelGGL(h->k.fast, dim3((unsigned)segs), dim3(64), 0, h->stream,
+                           hist, in4, out, flags, n_cplx, (int)n_sub, (int)spw, h->post);
+        SDRX_HIP(hipGetLastError());
+        snprintf(h->last_name, sizeof h->last_name, "%s", h->k.fast_name);
+        h->last_grid = (int)segs; h->last_block = 64; h->last_lds = h->k.fast_lds;
+    }
+    if (h->path != 2) {
+        const int cps = choose_cps(n_chunks, h->cus * 3);
+        const long segs = (n_chunks + cps - 1) / cps;
+        hipLaunchKernelGGL(h->k.fn, dim3((unsigned)segs), dim3(DC_THREADS), 0, h->stream,
+                           hist, in4, out, static_cast<const uint32_t*>(flags), n_cplx, (int)n_chunks, cps, h->post);
+        SDRX_HIP(hipGetLastError());
+        if (h->path == 1) {
+            snprintf(h->last_name, sizeof h->last_name, "%s", h->k.name);
+            h->last_grid = (int)segs; h->last_block = DC_THREADS; h->last_lds = h->k.lds;
+        }
+    }
     trc = h->timer.end(h->stream); if (trc) return trc;
     hipLaunchKernelGGL(hist_update_kernel, dim3(DC_CHUNK / 256), dim3(256), 0, h->stream,
                        h->d_hist[h->cur], reinterpret_cast<const uint32_t*>(d_iq), h->d_hist[h->cur ^ 1], n_cplx);
     SDRX_HIP(hipGetLastError());
     h->cur ^= 1;
-    snprintf(h->last_name, sizeof h->last_name, "%s", h->k.name);
-    h->last_grid = (int)segs; h->last_block = DC_THREADS; h->last_lds = h->k.lds;
     return SDRX_OK;
 }
 
@@ -174,6 +209,7 @@ int sdrx_decim_create(sdrx_decim_t** out, int device, int log2_decim, int fcpos,
     shifts(input_bits, log2_decim, &h->pre, &h->post);
     h->group = group_int16(log2_decim, fcpos);
     h->cus = device_cu_count(device);
+    { const char* pe = getenv("SDRX_DECIM_PATH"); h->path = !pe ? 0 : !strcmp(pe, "exact") ? 1 : !strcmp(pe, "fast") ? 2 : 0; }
     if (log2_decim > 0 && !pick(log2_decim, fcpos, h->pre, &h->k)) {
         delete h; set_error("sdrx_decim_create: no kernel for this configuration"); return SDRX_EINVAL;
     }
@@ -194,7 +230,7 @@ int sdrx_decim_destroy(sdrx_decim_t* h)
     (void)hipSetDevice(h->device);
     if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); }
     for (int i = 0; i < 2; i++) if (h->d_hist[i]) (void)hipFree(h->d_hist[i]);
-    h->d_in.release(); h->d_out.release(); h->timer.release();
+    h->d_in.release(); h->d_out.release(); h->d_flags.release(); h->timer.release();
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return SDRX_OK;

@@ -29,6 +29,22 @@ def test_decim_matches_oracle_split_calls(log2, fcpos, bits):
         assert np.array_equal(got, want), (log2, fcpos, bits, a, b, int((got != want).sum()))
 
 
+@pytest.mark.parametrize("path", ("fast", "exact"))
+@pytest.mark.parametrize("fcpos", (sa.FC_CEN, sa.FC_INF, sa.FC_SUP))
+@pytest.mark.parametrize("log2", range(1, 7))
+def test_each_kernel_path_alone(log2, fcpos, path, monkeypatch):
+    """SDRX_DECIM_PATH pins one kernel: `fast` = wave-private dot2 kernel WITHOUT its fallback (valid
+    on contract-honouring 12-bit data, where no int16 overflow can occur), `exact` = int32 kernel."""
+    monkeypatch.setenv("SDRX_DECIM_PATH", path)
+    n = 2 * 32768 + 4096 * 3 + 1024 + 256
+    x = orc.synth_iq(n, seed=500 + log2 + 7 * fcpos, amp=1400, tone=(0.0017, 600))
+    g = sa.Decimators(log2, fcpos, 12)
+    o = orc.Decim(log2, fcpos, 12)
+    for a, b in ((0, 2 * 5000), (2 * 5000, 2 * 70016), (2 * 70016, 2 * n)):
+        got, want = g.decimate(x[a:b]), o.process(x[a:b])
+        assert got.size == want.size and np.array_equal(got, want), (log2, fcpos, path, a)
+
+
 @pytest.mark.parametrize("fcpos", (sa.FC_CEN, sa.FC_INF))
 def test_decim64_full_scale_wrap(fcpos):
     """int16 extremes (-32768 everywhere, alternating full scale): exercises int32 wrap + non-mad24 stages."""
