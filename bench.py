@@ -112,21 +112,17 @@ def main():
     args = ap.parse_args()
 
     import sdrangel_amd as sa
+    from sdrangel_amd import shard
     sa.lib()                                    # before torch: one HIP runtime (see sdrangel_amd/__init__.py)
     import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(0)
+    rank, local, world = shard.world_from_env()
     dev = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    dist = shard.init_process_group("nccl", rank, world, device=dev) if world > 1 else None   # "nccl" == RCCL on ROCm
     n_gpus = world
+    my_streams = shard.streams_of_rank(n_gpus, rank, world)       # one stream per GPU: stream s -> GPU s
+    assert my_streams == [rank]
 
     B = args.batch
     g = torch.Generator(device=dev); g.manual_seed(5489 + rank)
@@ -158,28 +154,13 @@ def main():
         bytes_per_sample = 4.0 + 32 * 4.0 / 1024
         workload = f"cfg3: DownChannelizer bank, 32 channels (48 kS/s each) from one 61.44 MS/s-shaped stream per GPU, {B} samples per step"
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
     for _ in range(args.warmup):
         step()
-    barrier()
-    h.set_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
     torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
+    h.set_timing(True)
+    elapsed = shard.timed_region(step, args.steps, 0, lambda: torch.cuda.synchronize(dev), dist=dist, device=dev)
     k_ms, k_n = h.get_timing()
     h.set_timing(False)
-    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.barrier()
-    elapsed = float(el.item())
 
     if rank == 0:
         value = n_gpus * args.steps * B / elapsed / 1e6
@@ -202,7 +183,7 @@ def main():
         if n_gpus == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(8 * 1024 * 1024, 16)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,66 @@
+"""Deterministic synthetic int16 I/Q for fixtures and tests: pure integer arithmetic (a 64-bit LCG),
+so the same bytes come out on every numpy version / platform -- no RNG-stream stability assumed."""
+import numpy as np
+
+_A = np.uint64(6364136223846793005)
+_C = np.uint64(1442695040888963407)
+
+
+def lcg_u32(n: int, seed: int) -> np.ndarray:
+    """n pseudo-random uint32 (top half of a 64-bit LCG state), vectorised by jump-ahead in blocks."""
+    out = np.empty(n, np.uint32)
+    s = np.uint64(seed * 2 + 1)
+    # sequential in chunks of 1: too slow in python -> generate with a vectorised leapfrog of 4096 lanes
+    lanes = 4096
+    st = np.empty(lanes, np.uint64)
+    with np.errstate(over="ignore"):
+        for i in range(lanes):
+            s = s * _A + _C
+            st[i] = s
+        # multiplier/increment for a jump of `lanes` steps
+        a, c = np.uint64(1), np.uint64(0)
+        for _ in range(lanes):
+            c = c * _A + _C
+            a = a * _A
+        pos = 0
+        while pos < n:
+            m = min(lanes, n - pos)
+            out[pos:pos + m] = (st[:m] >> np.uint64(32)).astype(np.uint32)
+            st = st * a + c
+            pos += m
+    return out
+
+
+def noise_iq(n_cplx: int, seed: int, amp: int) -> np.ndarray:
+    """uniform int16 I/Q in [-amp, amp] (interleaved), amp <= 32767"""
+    u = lcg_u32(2 * n_cplx, seed).astype(np.int64)
+    return ((u % (2 * amp + 1)) - amp).astype(np.int16)
+
+
+# one period of an integer "tone" at fs/16: round(1000*cos/sin(2*pi*k/16)), hard-coded so no libm is involved
+_C16 = np.array([1000, 924, 707, 383, 0, -383, -707, -924, -1000, -924, -707, -383, 0, 383, 707, 924], np.int64)
+_S16 = np.roll(_C16, 4)
+
+
+def tone_iq(n_cplx: int, amp_milli: int, step: int = 1) -> np.ndarray:
+    """complex tone at step*fs/16 with amplitude amp_milli (table scaled by amp_milli/1000, integer division)"""
+    k = (np.arange(n_cplx, dtype=np.int64) * step) % 16
+    x = np.empty(2 * n_cplx, np.int64)
+    x[0::2] = _C16[k] * amp_milli // 1000
+    x[1::2] = _S16[k] * amp_milli // 1000
+    return x
+
+
+def mix(n_cplx: int, seed: int, amp: int, tone_amp: int = 0, step: int = 1) -> np.ndarray:
+    x = noise_iq(n_cplx, seed, amp).astype(np.int64)
+    if tone_amp:
+        x = x + tone_iq(n_cplx, tone_amp, step)
+    return np.clip(x, -32768, 32767).astype(np.int16)
+
+
+def fnv1a64(a: np.ndarray) -> int:
+    """FNV-1a over the little-endian bytes of a (used for the big golden outputs)"""
+    h = 0xcbf29ce484222325
+    for b in np.ascontiguousarray(a).view(np.uint8).tobytes():
+        h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return h
