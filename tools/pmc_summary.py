@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Fold rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/<tag>_traffic.json.
+usage: tools/pmc_summary.py gpurun_out/r01 r01 <batch_decim> <batch_chan>
+FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced
+streaming reads (MI355X_MICROARCH.md, HBM section), so the read side is doubled."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+src, tag, b_decim, b_chan = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+STEPS = int(sys.argv[5]) if len(sys.argv) > 5 else 4      # bench steps + warmup of the --pmc runs
+
+
+def fold(pattern):
+    acc = defaultdict(list)
+    for p in glob.glob(os.path.join(src, pattern, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(p)):
+            name = r["Kernel_Name"]
+            if "sdrx::" not in name:
+                continue
+            short = name.split("sdrx::")[1].split("(")[0]
+            acc[(short, r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return acc
+
+
+out = {"note": "bytes per launch; read = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB; separate --pmc passes", "kernels": []}
+for wl, batch, alg in (("decim64", b_decim, 4.0625), ("chan32", b_chan, 4.125)):
+    f = fold(f"pmc_fetch_{wl}"); w = fold(f"pmc_write_{wl}")
+    kernels = sorted({k for k, _ in list(f) + list(w)})
+    for k in kernels:
+        fv = f.get((k, "FETCH_SIZE"), []); wv = w.get((k, "WRITE_SIZE"), [])
+        if not fv and not wv:
+            continue
+        rd = 2 * 1024 * (sum(fv) / len(fv)) if fv else None
+        wr = 1024 * (sum(wv) / len(wv)) if wv else None
+        out["kernels"].append({"workload": wl, "kernel": k.replace(" ", ""), "batch_cplx": batch, "launches_seen": max(len(fv), len(wv)),
+                               "fetch_size_kib_raw": sum(fv) / len(fv) if fv else None,
+                               "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+                               "hbm_bytes_per_launch": (rd or 0) + (wr or 0),
+                               "hbm_bytes_per_step": ((2 * 1024 * sum(fv)) + 1024 * sum(wv)) / STEPS,
+                               "algorithmic_bytes_per_launch": alg * batch})
+json.dump(out, open(os.path.join("profiles", f"{tag}_traffic.json"), "w"), indent=1)
+for e in out["kernels"]:
+    print(e["workload"], e["kernel"], "hbm/launch %.1f MB" % (e["hbm_bytes_per_launch"] / 1e6), "hbm/step %.1f MB" % (e["hbm_bytes_per_step"] / 1e6), "alg/step %.1f MB" % (e["algorithmic_bytes_per_launch"] / 1e6))
