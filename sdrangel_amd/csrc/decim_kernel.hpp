@@ -72,13 +72,17 @@ void decim_chain_kernel(const uint4* __restrict__ hist,   // DC_CHUNK samples: t
     __shared__ __attribute__((aligned(16))) uint32_t lds[dc_lds_dwords(L)];
 
     const int tid = threadIdx.x;
-    const long first = (long)blockIdx.x * cps;
-    if (first >= n_chunks) return;
+    // Plain run (flags == nullptr): one workgroup per segment.  Fallback run behind the FAST kernel: a
+    // small grid strides over the segments and only works on those holding a flagged chunk, so clean
+    // input costs one short launch.
+    const long n_seg = (n_chunks + cps - 1) / cps;
+  for (long seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
+    const long first = seg * cps;
     long last = first + cps; if (last > n_chunks) last = n_chunks;
-    if (flags) {                                          // fallback run: only segments the FAST kernel flagged
+    if (flags) {
         bool any = false;
-        for (long c = first; c < last; ++c) any = any || flags[c] != 0;
-        if (!any) return;
+        for (long c = first + tid; c < last; c += NT) any = any || flags[c] != 0;
+        if (!__syncthreads_or(any)) continue;
     }
     const long n_in4 = n_in >> 2;                         // n_in is a multiple of 4 (group sizes are)
     const long n_out = n_in >> L;
@@ -161,6 +165,7 @@ void decim_chain_kernel(const uint4* __restrict__ hist,   // DC_CHUNK samples: t
         });
         __syncthreads();
     }
+  }   // segments
 }
 
 } // namespace sdrx

@@ -170,7 +170,8 @@ static int launch(sdrx_decim* h, const int16_t* d_iq, long n_cplx, int16_t* d_ou
     }
     if (h->path != 2) {
         const int cps = choose_cps(n_chunks, h->cus * 3);
-        const long segs = (n_chunks + cps - 1) / cps;
+        long segs = (n_chunks + cps - 1) / cps;
+        if (flags && segs > h->cus) segs = h->cus;       // fallback run: grid-stride scan of the flags
         hipLaunchKernelGGL(h->k.fn, dim3((unsigned)segs), dim3(DC_THREADS), 0, h->stream,
                            hist, in4, out, static_cast<const uint32_t*>(flags), n_cplx, (int)n_chunks, cps, h->post);
         SDRX_HIP(hipGetLastError());
