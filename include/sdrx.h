@@ -135,6 +135,42 @@ int sdrx_chan_bank_last_launch(const sdrx_chan_bank_t* h, char* kernel_name, int
                                int* grid, int* block, int* lds_bytes);
 
 /* ------------------------------------------------------------------------------------------
+ * Channel back-end bank: what every channelrx demod does with the DownChannelizer output before its
+ * audio-rate tail (plugins/channelrx/demodnfm/nfmdemod.cpp:150-163, demodssb/ssbdemod.cpp:158-172):
+ *     Complex c(re, im); c *= m_nco.nextIQ();                         NCO (sdrbase/dsp/nco.cpp:30-64)
+ *     if (m_interpolator.decimate(&dist, c, &ci)) { ... dist += step } Interpolator (interpolator.h:23-36)
+ *     n = filter->runSSB(ci, &sideband, usb) | runFilt(...)            fftfilt (fftfilt.cpp:261-325), g_fft
+ *     demod = m_phaseDiscri.phaseDiscriminatorDelta(...)               phasediscri.h:50-78
+ * One handle holds N channels; every feed produces that feed's outputs (like the demod's feed()
+ * running to completion), read them before the next feed.  float32, <= 1 ulp of the strict-IEEE
+ * scalar reference build (SURVEY.md finding 6).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sdrx_backend sdrx_backend_t;
+typedef struct sdrx_backend_cfg {
+    int32_t in_rate;         /* channelizer output rate: m_nco.setFreq(nco_freq, in_rate) */
+    int32_t nco_freq;        /* the demods pass -frequencyOffset of MsgChannelizerNotification */
+    int32_t out_rate;        /* audio / demod rate; distance step = (Real) in_rate / (Real) out_rate; <= in_rate */
+    float   interp_cutoff;   /* m_interpolator.create(16, in_rate, interp_cutoff, taps_per_phase) */
+    float   taps_per_phase;  /* 4.5 (default, NFM) or 2.0 (SSB) */
+    int32_t filt_mode;       /* 0 none, 1 runFilt, 2 runSSB usb, 3 runSSB lsb  (getDC = true) */
+    float   f1, f2;          /* fftfilt(f1, f2, 1024): normalised to the OUTPUT rate */
+    int32_t discri;          /* 0 none, 1 phaseDiscriminatorDelta (NFM), 2 phaseDiscriminator (UDPSrc) */
+    float   fm_scaling;      /* setFMScaling */
+} sdrx_backend_cfg;
+int sdrx_backend_create(sdrx_backend_t** out, int device, int32_t n_ch, const sdrx_backend_cfg* cfg);
+int sdrx_backend_destroy(sdrx_backend_t* h);
+/* iq[c] / n_per_ch[c]: channel c's new samples (what DownChannelizer handed to m_sampleSink->feed) */
+int sdrx_backend_feed(sdrx_backend_t* h, const int16_t* const* iq, const int64_t* n_per_ch);
+int sdrx_backend_feed_dev(sdrx_backend_t* h, const int16_t* const* d_iq, const int64_t* n_per_ch);
+/* outputs of the last feed for channel ch: complex (re,im pairs) unless a discriminator is on;
+ * returns the number of FLOATS written (<0: error) */
+int64_t sdrx_backend_read(sdrx_backend_t* h, int32_t ch, float* out, int64_t cap_floats);
+/* design products, for inspection: polyphase taps [16][ntaps], filter spectrum (1024 complex), NCO increment */
+int sdrx_backend_get_design(sdrx_backend_t* h, int32_t ch, int32_t* ntaps_per_phase, float* taps, int32_t taps_cap,
+                            float* filter_iq, int32_t* nco_inc);
+int sdrx_backend_sync(sdrx_backend_t* h);
+
+/* ------------------------------------------------------------------------------------------
  * SampleSinkFifo (sdrbase/dsp/samplesinkfifo.{h,cpp}) -- host ring of `Sample`, same
  * write / readBegin / readCommit contract, minus the Qt signal (a callback instead of dataReady()).
  * ------------------------------------------------------------------------------------------ */

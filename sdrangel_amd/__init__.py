@@ -88,6 +88,13 @@ def lib() -> C.CDLL:
         "sdrx_chan_bank_set_timing": (C.c_int, [vp, C.c_int]),
         "sdrx_chan_bank_get_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i64), C.c_int]),
         "sdrx_chan_bank_last_launch": (C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "sdrx_backend_create": (C.c_int, [pp, C.c_int, i32, vp]),
+        "sdrx_backend_destroy": (C.c_int, [vp]),
+        "sdrx_backend_feed": (C.c_int, [vp, vp, vp]),
+        "sdrx_backend_feed_dev": (C.c_int, [vp, vp, vp]),
+        "sdrx_backend_read": (i64, [vp, i32, vp, i64]),
+        "sdrx_backend_get_design": (C.c_int, [vp, i32, C.POINTER(i32), vp, i32, vp, C.POINTER(i32)]),
+        "sdrx_backend_sync": (C.c_int, [vp]),
         "sdrx_fifo_create": (C.c_int, [pp, u32]),
         "sdrx_fifo_destroy": (C.c_int, [vp]),
         "sdrx_fifo_set_size": (C.c_int, [vp, u32]),
@@ -276,6 +283,57 @@ class ChannelizerBank:
         g, b, l = C.c_int(), C.c_int(), C.c_int()
         _check(lib().sdrx_chan_bank_last_launch(self._h, name, 128, C.byref(g), C.byref(b), C.byref(l)), "last_launch")
         return {"kernel": name.value.decode(), "grid": g.value, "block": b.value, "lds_bytes": l.value}
+
+
+class BackendCfg(C.Structure):
+    """sdrx_backend_cfg"""
+    _fields_ = [("in_rate", C.c_int32), ("nco_freq", C.c_int32), ("out_rate", C.c_int32),
+                ("interp_cutoff", C.c_float), ("taps_per_phase", C.c_float), ("filt_mode", C.c_int32),
+                ("f1", C.c_float), ("f2", C.c_float), ("discri", C.c_int32), ("fm_scaling", C.c_float)]
+
+
+class BackendBank:
+    """NCO -> Interpolator -> fftfilt -> discriminator for N channels (front of the channelrx demods)."""
+
+    def __init__(self, cfgs, device: int = 0):
+        self.n_ch = len(cfgs)
+        arr = (BackendCfg * self.n_ch)(*cfgs)
+        self._h = C.c_void_p()
+        _check(lib().sdrx_backend_create(C.byref(self._h), device, self.n_ch, arr), "sdrx_backend_create")
+        self.cfgs = list(cfgs)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sdrx_backend_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def feed(self, per_channel_iq):
+        bufs = [_i16(x) for x in per_channel_iq]
+        ptrs = (C.c_void_p * self.n_ch)(*[b.ctypes.data for b in bufs])
+        ns = (C.c_int64 * self.n_ch)(*[b.size // 2 for b in bufs])
+        _check(lib().sdrx_backend_feed(self._h, ptrs, ns), "sdrx_backend_feed")
+
+    def feed_dev(self, ptrs, counts):
+        p = (C.c_void_p * self.n_ch)(*ptrs)
+        n = (C.c_int64 * self.n_ch)(*counts)
+        _check(lib().sdrx_backend_feed_dev(self._h, p, n), "sdrx_backend_feed_dev")
+
+    def read(self, ch: int, cap_floats: int = 1 << 24) -> np.ndarray:
+        out = np.empty(cap_floats, np.float32)
+        n = lib().sdrx_backend_read(self._h, ch, out.ctypes.data, cap_floats)
+        if n < 0:
+            raise SdrxError(f"sdrx_backend_read rc={n}: {lib().sdrx_last_error().decode()}")
+        return out[:n].copy()
+
+    def design(self, ch: int):
+        nt, inc = C.c_int32(), C.c_int32()
+        taps = np.zeros(16 * 256, np.float32)
+        filt = np.zeros(2048, np.float32)
+        _check(lib().sdrx_backend_get_design(self._h, ch, C.byref(nt), taps.ctypes.data, taps.size, filt.ctypes.data, C.byref(inc)),
+               "sdrx_backend_get_design")
+        return nt.value, taps[: 16 * nt.value].copy(), filt, inc.value
 
 
 class SampleSinkFifo:

@@ -1,0 +1,342 @@
+// libsdrx.so: sdrx_backend_* -- per-channel NCO -> Interpolator -> fftfilt -> discriminator bank, the
+// common front of the channelrx demods' feed() (nfmdemod.cpp:150-163, ssbdemod.cpp:158-172).
+// Host side: filter / tap / table design exactly as the reference does it at configure time
+// (Interpolator::create interpolator.cpp:21-129, fftfilt::create_filter fftfilt.cpp:108-146,
+// NCO::initTable nco.cpp:30-39, g_fft::fftCosInit gfft.h:141-150), launches, state bookkeeping.
+#include "sdrx_common.hpp"
+#include "backend_kernels.hpp"
+#include <vector>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <algorithm>
+
+using namespace sdrx;
+
+namespace {
+
+const double PI_D = 3.14159265358979323846;
+
+// Interpolator::createPolyphaseLowPass + reorder + per-phase normalisation
+void design_interp(int phase_steps, double sample_rate, double cutoff, double tpp, std::vector<float>& poly, int* ntaps_per_phase)
+{
+    double gain = 1.0;
+    const double fs = phase_steps * sample_rate;
+    int ntaps = (int)(tpp * phase_steps);
+    if ((ntaps % 2) != 0) ntaps++;
+    ntaps *= phase_steps;
+    std::vector<float> taps((size_t)ntaps, 0.0f), window((size_t)ntaps);
+    for (int n = 0; n < ntaps; n++) window[(size_t)n] = (float)(0.54 - 0.46 * std::cos((2 * PI_D * n) / (ntaps - 1)));
+    const int M = (ntaps - 1) / 2;
+    const double fwT0 = 2 * PI_D * cutoff / fs;
+    for (int n = -M; n <= M; n++) {
+        if (n == 0) taps[(size_t)(n + M)] = (float)(fwT0 / PI_D * window[(size_t)(n + M)]);
+        else taps[(size_t)(n + M)] = (float)(std::sin(n * fwT0) / (n * PI_D) * window[(size_t)(n + M)]);
+    }
+    double mx = taps[(size_t)M];
+    for (int n = 1; n <= M; n++) mx += 2.0 * taps[(size_t)(n + M)];
+    gain /= mx;
+    for (int i = 0; i < ntaps; i++) taps[(size_t)i] = (float)(taps[(size_t)i] * gain);
+    const int nt = ntaps / phase_steps;
+    poly.assign((size_t)ntaps, 0.0f);
+    for (int ph = 0; ph < phase_steps; ph++)
+        for (int i = 0; i < nt; i++) poly[(size_t)(ph * nt + i)] = taps[(size_t)(i * phase_steps + ph)];
+    for (int ph = 0; ph < phase_steps; ph++) {
+        float sum = 0;
+        for (int i = 0; i < nt; i++) sum += poly[(size_t)(ph * nt + i)];
+        for (int i = 0; i < nt; i++) poly[(size_t)(ph * nt + i)] /= sum;
+    }
+    *ntaps_per_phase = nt;
+}
+
+float fsinc(float fc, int i, int len)
+{
+    const int len2 = len / 2;
+    return (i == len2) ? (float)(2.0 * fc) : (float)(std::sin(2 * PI_D * fc * (i - len2)) / (PI_D * (i - len2)));
+}
+float blackman(int i, int len)
+{
+    return (float)(0.42 - 0.50 * std::cos(2.0 * PI_D * i / len) + 0.08 * std::cos(4.0 * PI_D * i / len));
+}
+
+struct ChanHost {
+    sdrx_backend_cfg cfg;
+    DevBuf mixed, sched, res, head, tail, cplx_out, real_out;
+    uint32_t* hist[2] = { nullptr, nullptr };
+    int cur = 0;
+    int64_t cap_in = 0;
+    DevBuf stage_in;              // host-pointer feeds
+};
+
+} // namespace
+
+struct sdrx_backend {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    int n_ch = 0;
+    std::vector<ChanHost> ch;
+    std::vector<BeChan> h_chan;   // host mirror of the config part (state lives on the device)
+    BeChan* d_chan = nullptr;
+    BeBufs* d_bufs = nullptr;
+    std::vector<BeBufs> h_bufs;
+    float* d_nco = nullptr; float* d_taps = nullptr; float2* d_filters = nullptr; float* d_utbl = nullptr;
+    std::vector<float> taps_all; std::vector<float> filters_all;     // kept for inspection (tests)
+    std::vector<int> taps_off, filt_off, ntaps;
+    bool state_valid = false;     // d_chan state initialised
+};
+
+static int ensure_capacity(sdrx_backend* b, int c, int64_t n_in)
+{
+    ChanHost& h = b->ch[(size_t)c];
+    if (n_in <= h.cap_in) return SDRX_OK;
+    int64_t cap = h.cap_in ? h.cap_in : 4096;
+    while (cap < n_in) cap *= 2;
+    // pending (<512) + at most one resampler output per input (distance step >= 1 by construction of decimate())
+    const size_t n_res_max = (size_t)cap + 1024;
+    const size_t n_blk_max = n_res_max / (BE_FFT / 2) + 2;
+    // buffers that carry state (res: pending, tail: ovlbuf) must keep their content
+    auto grow_keep = [&](DevBuf& buf, size_t bytes, size_t keep) -> int {
+        if (bytes <= buf.cap) return SDRX_OK;
+        void* np = nullptr;
+        SDRX_HIP(hipMalloc(&np, bytes));
+        SDRX_HIP(hipMemsetAsync(np, 0, bytes, b->stream));
+        if (buf.p && keep) SDRX_HIP(hipMemcpyAsync(np, buf.p, keep, hipMemcpyDeviceToDevice, b->stream));
+        SDRX_HIP(hipStreamSynchronize(b->stream));
+        if (buf.p) (void)hipFree(buf.p);
+        buf.p = np; buf.cap = bytes;
+        return SDRX_OK;
+    };
+    int rc;
+    if ((rc = grow_keep(h.mixed, (size_t)(BE_HIST + cap) * 8, 0))) return rc;
+    if ((rc = grow_keep(h.sched, n_res_max * 4, 0))) return rc;
+    if ((rc = grow_keep(h.res, n_res_max * 8, (BE_FFT / 2) * 8))) return rc;
+    if ((rc = grow_keep(h.head, n_blk_max * (BE_FFT / 2) * 8, 0))) return rc;
+    if ((rc = grow_keep(h.tail, (n_blk_max + 1) * (BE_FFT / 2) * 8, (BE_FFT / 2) * 8))) return rc;
+    if ((rc = grow_keep(h.cplx_out, n_res_max * 8, 0))) return rc;
+    if ((rc = grow_keep(h.real_out, n_res_max * 4, 0))) return rc;
+    h.cap_in = cap;
+    return SDRX_OK;
+}
+
+extern "C" {
+
+int sdrx_backend_destroy(sdrx_backend_t* b)
+{
+    if (!b) return SDRX_OK;
+    (void)hipSetDevice(b->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    for (auto& h : b->ch) {
+        h.mixed.release(); h.sched.release(); h.res.release(); h.head.release(); h.tail.release();
+        h.cplx_out.release(); h.real_out.release(); h.stage_in.release();
+        for (int i = 0; i < 2; i++) if (h.hist[i]) (void)hipFree(h.hist[i]);
+    }
+    if (b->d_chan) (void)hipFree(b->d_chan);
+    if (b->d_bufs) (void)hipFree(b->d_bufs);
+    if (b->d_nco) (void)hipFree(b->d_nco);
+    if (b->d_taps) (void)hipFree(b->d_taps);
+    if (b->d_filters) (void)hipFree(b->d_filters);
+    if (b->d_utbl) (void)hipFree(b->d_utbl);
+    if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
+    delete b;
+    return SDRX_OK;
+}
+
+int sdrx_backend_create(sdrx_backend_t** out, int device, int32_t n_ch, const sdrx_backend_cfg* cfg)
+{
+    if (!out) { set_error("sdrx_backend_create: null out"); return SDRX_EINVAL; }
+    *out = nullptr;
+    if (n_ch <= 0 || !cfg) { set_error("sdrx_backend_create: bad argument"); return SDRX_EINVAL; }
+    for (int c = 0; c < n_ch; c++) {
+        const sdrx_backend_cfg& k = cfg[c];
+        if (k.in_rate <= 0 || k.out_rate <= 0 || k.out_rate > k.in_rate || k.filt_mode < 0 || k.filt_mode > 3 ||
+            k.discri < 0 || k.discri > 2 || k.taps_per_phase <= 0 || k.taps_per_phase * 16 > BE_HIST) {
+            set_error("sdrx_backend_create: bad channel configuration (need out_rate <= in_rate, taps_per_phase*16 <= 256)");
+            return SDRX_EINVAL;
+        }
+    }
+    int rc = check_device(device); if (rc) return rc;
+    SDRX_HIP(hipSetDevice(device));
+    sdrx_backend* b = new (std::nothrow) sdrx_backend;
+    if (!b) return SDRX_ENOMEM;
+    b->device = device; b->n_ch = n_ch;
+    hipError_t e = hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete b; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
+    b->stream = b->own_stream;
+    b->ch.resize((size_t)n_ch); b->h_chan.resize((size_t)n_ch); b->h_bufs.resize((size_t)n_ch);
+    b->taps_off.resize((size_t)n_ch); b->filt_off.resize((size_t)n_ch); b->ntaps.resize((size_t)n_ch);
+
+#define BE_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int r_ = hip_fail(e_, #call, __FILE__, __LINE__); sdrx_backend_destroy(b); return r_; } } while (0)
+    // NCO table (nco.cpp:30-39) and g_fft cosine table (gfft.h:141-150)
+    std::vector<float> nco(BE_NCO_N), utbl(BE_FFT / 4 + 1);
+    for (int i = 0; i < BE_NCO_N; i++) nco[(size_t)i] = (float)std::cos((2.0 * PI_D * i) / BE_NCO_N);
+    utbl[0] = 1.0f;
+    for (int i = 1; i < BE_FFT / 4; i++) utbl[(size_t)i] = (float)std::cos((2.0 * 3.141592653589793238462643383279502884197 * (float)i) / (float)BE_FFT);
+    utbl[BE_FFT / 4] = 0.0f;
+    BE_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_nco), BE_NCO_N * 4));
+    BE_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_utbl), (BE_FFT / 4 + 1) * 4));
+    BE_TRY(hipMemcpy(b->d_nco, nco.data(), BE_NCO_N * 4, hipMemcpyHostToDevice));
+    BE_TRY(hipMemcpy(b->d_utbl, utbl.data(), (BE_FFT / 4 + 1) * 4, hipMemcpyHostToDevice));
+
+    // per channel design
+    BE_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_filters), (size_t)n_ch * BE_FFT * 8));
+    b->filters_all.assign((size_t)n_ch * BE_FFT * 2, 0.0f);
+    for (int c = 0; c < n_ch; c++) {
+        const sdrx_backend_cfg& k = cfg[c];
+        ChanHost& h = b->ch[(size_t)c];
+        h.cfg = k;
+        std::vector<float> poly; int nt = 0;
+        design_interp(16, (double)k.in_rate, (double)k.interp_cutoff, (double)k.taps_per_phase, poly, &nt);
+        b->taps_off[(size_t)c] = (int)b->taps_all.size(); b->ntaps[(size_t)c] = nt;
+        b->taps_all.insert(b->taps_all.end(), poly.begin(), poly.end());
+        b->filt_off[(size_t)c] = c * BE_FFT;
+        if (k.filt_mode) {
+            // fftfilt::create_filter: windowed sinc in the first flen2 bins, forward FFT (on the GPU, with the
+            // same kernel code the data path uses), normalise to max |H| over bins 0..flen2-1
+            std::vector<float> f((size_t)BE_FFT * 2, 0.0f);
+            const int h2 = BE_FFT / 2;
+            const bool lp = k.f2 != 0, hp = k.f1 != 0;
+            for (int i = 0; i < h2; i++) {
+                float v = 0;
+                if (lp) v += fsinc(k.f2, i, h2);
+                if (hp) v -= fsinc(k.f1, i, h2);
+                f[(size_t)(2 * i)] = v;
+            }
+            if (hp && k.f2 < k.f1) f[(size_t)(2 * (h2 / 2))] += 1;
+            for (int i = 0; i < h2; i++) { const float w = blackman(i, h2); f[(size_t)(2 * i)] *= w; f[(size_t)(2 * i + 1)] *= w; }
+            float2* dst = b->d_filters + (size_t)c * BE_FFT;
+            BE_TRY(hipMemcpy(dst, f.data(), BE_FFT * 8, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(be_fft_design_kernel, dim3(1), dim3(128), 0, b->stream, dst, b->d_utbl);
+            BE_TRY(hipGetLastError());
+            BE_TRY(hipStreamSynchronize(b->stream));
+            BE_TRY(hipMemcpy(f.data(), dst, BE_FFT * 8, hipMemcpyDeviceToHost));
+            float scale = 0;
+            for (int i = 0; i < h2; i++) { const float mag = hypotf(f[(size_t)(2 * i)], f[(size_t)(2 * i + 1)]); if (mag > scale) scale = mag; }
+            if (scale != 0) for (int i = 0; i < BE_FFT * 2; i++) f[(size_t)i] /= scale;
+            BE_TRY(hipMemcpy(dst, f.data(), BE_FFT * 8, hipMemcpyHostToDevice));
+            std::memcpy(&b->filters_all[(size_t)c * BE_FFT * 2], f.data(), BE_FFT * 8);
+        }
+        BeChan& s = b->h_chan[(size_t)c];
+        std::memset(&s, 0, sizeof s);
+        s.nco_inc = (int)(((float)k.nco_freq * BE_NCO_N) / (float)k.in_rate);          // NCO::setFreq (float math, truncation)
+        s.step = (float)k.in_rate / (float)k.out_rate;
+        s.ntaps = nt; s.phase_steps = 16;
+        s.taps_off = b->taps_off[(size_t)c]; s.filt_mode = k.filt_mode; s.filt_off = b->filt_off[(size_t)c];
+        s.discri = k.discri; s.fm_scaling = k.fm_scaling;
+        for (int i = 0; i < 2; i++) {
+            BE_TRY(hipMalloc(reinterpret_cast<void**>(&h.hist[i]), BE_HIST * 4));
+            BE_TRY(hipMemset(h.hist[i], 0, BE_HIST * 4));
+        }
+    }
+    BE_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_taps), b->taps_all.size() * 4));
+    BE_TRY(hipMemcpy(b->d_taps, b->taps_all.data(), b->taps_all.size() * 4, hipMemcpyHostToDevice));
+    BE_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_chan), (size_t)n_ch * sizeof(BeChan)));
+    BE_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_bufs), (size_t)n_ch * sizeof(BeBufs)));
+    BE_TRY(hipMemcpy(b->d_chan, b->h_chan.data(), (size_t)n_ch * sizeof(BeChan), hipMemcpyHostToDevice));
+#undef BE_TRY
+    *out = b;
+    return SDRX_OK;
+}
+
+static int feed_common(sdrx_backend* b, const int16_t* const* d_iq, const int64_t* n_per_ch)
+{
+    int64_t n_max = 0;
+    for (int c = 0; c < b->n_ch; c++) {
+        if (n_per_ch[c] < 0 || n_per_ch[c] > 0x3fffffff) { set_error("sdrx_backend_feed: bad length"); return SDRX_EINVAL; }
+        int rc = ensure_capacity(b, c, std::max<int64_t>(n_per_ch[c], 1)); if (rc) return rc;
+        n_max = std::max(n_max, n_per_ch[c]);
+    }
+    // per-feed fields: n_in goes into the device-side BeChan (the rest of it is state we must not touch)
+    std::vector<int> n_in((size_t)b->n_ch);
+    for (int c = 0; c < b->n_ch; c++) {
+        ChanHost& h = b->ch[(size_t)c];
+        BeBufs& u = b->h_bufs[(size_t)c];
+        u.in = reinterpret_cast<const uint32_t*>(d_iq[c]);
+        u.hist = h.hist[h.cur]; u.hist_next = h.hist[h.cur ^ 1];
+        u.mixed = static_cast<float2*>(h.mixed.p); u.sched = static_cast<uint32_t*>(h.sched.p);
+        u.res = static_cast<float2*>(h.res.p); u.head = static_cast<float2*>(h.head.p); u.tail = static_cast<float2*>(h.tail.p);
+        u.cplx_out = static_cast<float2*>(h.cplx_out.p); u.real_out = static_cast<float*>(h.real_out.p);
+        n_in[(size_t)c] = (int)n_per_ch[c];
+        SDRX_HIP(hipMemcpyAsync(reinterpret_cast<char*>(b->d_chan + c) + offsetof(BeChan, n_in), &n_in[(size_t)c], 4,
+                                hipMemcpyHostToDevice, b->stream));
+    }
+    SDRX_HIP(hipMemcpyAsync(b->d_bufs, b->h_bufs.data(), (size_t)b->n_ch * sizeof(BeBufs), hipMemcpyHostToDevice, b->stream));
+    SDRX_HIP(hipStreamSynchronize(b->stream));            // n_in / h_bufs are stack/host vectors: copies must be done before we return
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, (n_max + BE_HIST + 255) / 256));
+    hipLaunchKernelGGL(be_schedule_kernel, dim3((unsigned)((b->n_ch + 63) / 64)), dim3(64), 0, b->stream, b->d_chan, b->d_bufs, b->n_ch);
+    SDRX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(be_mix_kernel, dim3(gx, (unsigned)b->n_ch), dim3(256), 0, b->stream, b->d_chan, b->d_bufs, b->d_nco);
+    SDRX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(be_fir_kernel, dim3(gx, (unsigned)b->n_ch), dim3(256), 0, b->stream, b->d_chan, b->d_bufs, b->d_taps);
+    SDRX_HIP(hipGetLastError());
+    const unsigned max_blocks = (unsigned)((n_max + 1024) / (BE_FFT / 2) + 1);
+    hipLaunchKernelGGL(be_fft_kernel, dim3(max_blocks, (unsigned)b->n_ch), dim3(128), 0, b->stream, b->d_chan, b->d_bufs, b->d_filters, b->d_utbl);
+    SDRX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(be_finish_kernel, dim3(gx, (unsigned)b->n_ch), dim3(256), 0, b->stream, b->d_chan, b->d_bufs);
+    SDRX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(be_carry_kernel, dim3((unsigned)b->n_ch), dim3(256), 0, b->stream, b->d_chan, b->d_bufs);
+    SDRX_HIP(hipGetLastError());
+    for (auto& h : b->ch) h.cur ^= 1;
+    return SDRX_OK;
+}
+
+int sdrx_backend_feed_dev(sdrx_backend_t* b, const int16_t* const* d_iq, const int64_t* n_per_ch)
+{
+    if (!b || !d_iq || !n_per_ch) { set_error("sdrx_backend_feed_dev: null argument"); return SDRX_EINVAL; }
+    SDRX_HIP(hipSetDevice(b->device));
+    return feed_common(b, d_iq, n_per_ch);
+}
+
+int sdrx_backend_feed(sdrx_backend_t* b, const int16_t* const* iq, const int64_t* n_per_ch)
+{
+    if (!b || !iq || !n_per_ch) { set_error("sdrx_backend_feed: null argument"); return SDRX_EINVAL; }
+    SDRX_HIP(hipSetDevice(b->device));
+    SDRX_HIP(hipStreamSynchronize(b->stream));
+    std::vector<const int16_t*> d((size_t)b->n_ch);
+    for (int c = 0; c < b->n_ch; c++) {
+        ChanHost& h = b->ch[(size_t)c];
+        int rc = h.stage_in.reserve((size_t)std::max<int64_t>(n_per_ch[c], 1) * 4); if (rc) return rc;
+        if (n_per_ch[c] > 0) SDRX_HIP(hipMemcpyAsync(h.stage_in.p, iq[c], (size_t)n_per_ch[c] * 4, hipMemcpyHostToDevice, b->stream));
+        d[(size_t)c] = static_cast<const int16_t*>(h.stage_in.p);
+    }
+    return feed_common(b, d.data(), n_per_ch);
+}
+
+int64_t sdrx_backend_read(sdrx_backend_t* b, int32_t c, float* out, int64_t cap_floats)
+{
+    if (!b || c < 0 || c >= b->n_ch || cap_floats < 0 || (cap_floats > 0 && !out)) { set_error("sdrx_backend_read: bad argument"); return SDRX_EINVAL; }
+    if (hipSetDevice(b->device) != hipSuccess) return SDRX_EHIP;
+    BeChan s;
+    hipError_t e = hipMemcpyAsync(&s, b->d_chan + c, sizeof s, hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    if (e != hipSuccess) return hip_fail(e, "read state", __FILE__, __LINE__);
+    const bool real = s.discri != 0;
+    int64_t n_floats = (int64_t)s.n_out * (real ? 1 : 2);
+    if (n_floats > cap_floats) n_floats = cap_floats;
+    if (n_floats == 0) return 0;
+    const void* src = real ? b->ch[(size_t)c].real_out.p : b->ch[(size_t)c].cplx_out.p;
+    e = hipMemcpy(out, src, (size_t)n_floats * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "read data", __FILE__, __LINE__);
+    return n_floats;
+}
+
+int sdrx_backend_get_design(sdrx_backend_t* b, int32_t c, int32_t* ntaps_per_phase, float* taps, int32_t taps_cap,
+                            float* filter_iq, int32_t* nco_inc)
+{
+    if (!b || c < 0 || c >= b->n_ch) { set_error("sdrx_backend_get_design: bad channel"); return SDRX_EINVAL; }
+    const int nt = b->ntaps[(size_t)c];
+    if (ntaps_per_phase) *ntaps_per_phase = nt;
+    if (taps) std::memcpy(taps, &b->taps_all[(size_t)b->taps_off[(size_t)c]], (size_t)std::min(taps_cap, nt * 16) * 4);
+    if (filter_iq) std::memcpy(filter_iq, &b->filters_all[(size_t)c * BE_FFT * 2], BE_FFT * 8);
+    if (nco_inc) *nco_inc = b->h_chan[(size_t)c].nco_inc;
+    return SDRX_OK;
+}
+
+int sdrx_backend_sync(sdrx_backend_t* b)
+{
+    if (!b) return SDRX_EINVAL;
+    SDRX_HIP(hipSetDevice(b->device));
+    SDRX_HIP(hipStreamSynchronize(b->stream));
+    return SDRX_OK;
+}
+
+} // extern "C"

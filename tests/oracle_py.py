@@ -34,6 +34,64 @@ def _sig(L):
     L.sdro_chain_feed.restype = i64; L.sdro_chain_feed.argtypes = [vp, vp, i64, vp]
 
 
+def _sig_float(L):
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    L.sdro_nco_table.argtypes = [vp]
+    L.sdro_nco_inc.restype = i32; L.sdro_nco_inc.argtypes = [f32, f32]
+    L.sdro_backend_new.restype = vp; L.sdro_backend_new.argtypes = [f32, f32, f32, i32, f32, f32]
+    L.sdro_backend_free.argtypes = [vp]
+    L.sdro_backend_feed.restype = i64; L.sdro_backend_feed.argtypes = [vp, vp, i64, vp]
+    L.sdro_backend_ntaps.restype = i32; L.sdro_backend_ntaps.argtypes = [vp]
+    L.sdro_backend_taps.restype = C.POINTER(C.c_float); L.sdro_backend_taps.argtypes = [vp]
+    L.sdro_gfft.argtypes = [vp, i32, i32]
+    L.sdro_fftfilt_new.restype = vp; L.sdro_fftfilt_new.argtypes = [f32, f32, i32]
+    L.sdro_fftfilt_free.argtypes = [vp]
+    L.sdro_fftfilt_filter.restype = C.POINTER(C.c_float); L.sdro_fftfilt_filter.argtypes = [vp]
+    L.sdro_fftfilt_run.restype = i64; L.sdro_fftfilt_run.argtypes = [vp, i32, vp, i64, vp]
+    L.sdro_discri.argtypes = [i32, f32, vp, i64, vp]
+
+
+class Backend:
+    """oracle of one channel's NCO -> Interpolator -> [fftfilt] -> [discriminator] chain, streaming"""
+
+    def __init__(self, in_rate, nco_freq, out_rate, cutoff, tpp, filt_mode=0, f1=0.0, f2=0.0, discri=0, fm_scaling=1.0):
+        L = lib(); _sig_float(L)
+        self.L = L
+        self.b = L.sdro_backend_new(float(nco_freq), float(in_rate), float(out_rate), 16, cutoff, tpp)
+        self.f = L.sdro_fftfilt_new(f1, f2, 1024) if filt_mode else None
+        self.filt_mode, self.discri, self.fm = filt_mode, discri, fm_scaling
+        self.last = None      # last sample seen by the discriminator (carried state)
+        self.prev_tail = np.zeros(0, np.float32)
+
+    def taps(self):
+        nt = self.L.sdro_backend_ntaps(self.b)
+        return nt, np.ctypeslib.as_array(self.L.sdro_backend_taps(self.b), shape=(16 * nt,)).copy()
+
+    def filter(self):
+        return np.ctypeslib.as_array(self.L.sdro_fftfilt_filter(self.f), shape=(2048,)).copy()
+
+    def feed(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.int16)
+        n = iq.size // 2
+        res = np.empty(2 * n + 8, np.float32)
+        k = self.L.sdro_backend_feed(self.b, iq.ctypes.data, n, res.ctypes.data)
+        x = res[: 2 * k].copy()
+        if self.filt_mode:
+            y = np.empty(x.size + 2048, np.float32)
+            m = self.L.sdro_fftfilt_run(self.f, self.filt_mode - 1, x.ctypes.data, k, y.ctypes.data)   # 1 runFilt, 2 usb, 3 lsb -> 0, 1, 2
+            x = y[: 2 * m].copy()
+        if not self.discri:
+            return x
+        # the oracle's discriminator function is stateless per call: replay it over (carried sample + new ones)
+        full = np.concatenate([self.prev_tail, x]).astype(np.float32)
+        out = np.empty(full.size // 2 + 1, np.float32)
+        self.L.sdro_discri(self.discri - 1, self.fm, full.ctypes.data, full.size // 2, out.ctypes.data)
+        skip = self.prev_tail.size // 2
+        if x.size:
+            self.prev_tail = x[-2:].copy()
+        return out[skip: full.size // 2].copy()
+
+
 class Decim:
     def __init__(self, log2, fcpos, bits, fast=False):
         self.L = lib(fast)
