@@ -261,6 +261,12 @@ class ChannelizerBank:
             raise SdrxError(f"sdrx_chan_bank_read rc={n}: {lib().sdrx_last_error().decode()}")
         return out[: 2 * n]
 
+    def last_dev(self, ch: int):
+        """(device pointer, n_cplx) of what the last feed produced for channel ch"""
+        p, n = C.c_void_p(), C.c_int64()
+        _check(lib().sdrx_chan_bank_last_dev(self._h, ch, C.byref(p), C.byref(n)), "sdrx_chan_bank_last_dev")
+        return p.value or 0, n.value
+
     def skip(self, ch: int, n: int = -1) -> int:
         return lib().sdrx_chan_bank_skip(self._h, ch, n)
 

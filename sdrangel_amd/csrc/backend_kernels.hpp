@@ -127,7 +127,17 @@ __global__ void be_fir_kernel(const BeChan* __restrict__ ch, const BeBufs* __res
     }
 }
 
-// ---- g_fft network on a 1024-point block held in LDS (see oracle/sdro_float.c for the derivation)
+// ---- g_fft network on a 1024-point block held in LDS.
+// John Green's FFT as the reference runs it for N = 1024 (gfft.h: ffts1 :1189-1224, iffts1 :2238-2275):
+// bit-reversed load fused with one radix-2 stage (bitrevR2 :185-317; scbitrevR2 :1231-1363 scales by 1/N),
+// then three radix-8 passes (bfstages :843-1158 / ibfstages :1889-2209) with D = 2, 16, 128.  The reference's
+// in-place index choreography does not change values; the arithmetic FORMS do.  With multiplier m = (mr, mi):
+//     PLUS (a,b,m): r = (a.r + b.r*mr) - b.i*mi ;  i = (a.i + b.r*mi) + b.i*mr      (= a + b*m)
+//     MINUS(a,b,m): r = (a.r - b.r*mr) + b.i*mi ;  i = (a.i - b.r*mi) - b.i*mr      (= a - b*m)
+//     and the partner of every butterfly is formed as 2*a - result.
+// Forward multipliers are conj(w), i*conj(w); inverse ones their conjugates (IEEE negation is exact, so a
+// sign flip of mi reproduces the reference's explicit +/- variants bit for bit).  Twiddles come from the
+// quarter-wave float cosine table of fftCosInit (:141-150); w0 crosses pi/2 at u = D/2 and is mirrored.
 __device__ __forceinline__ float2 c_plus(float2 a, float2 b, float mr, float mi)  { float2 t; t.x = (a.x + b.x * mr) - b.y * mi; t.y = (a.y + b.x * mi) + b.y * mr; return t; }
 __device__ __forceinline__ float2 c_minus(float2 a, float2 b, float mr, float mi) { float2 t; t.x = (a.x - b.x * mr) + b.y * mi; t.y = (a.y - b.x * mi) - b.y * mr; return t; }
 __device__ __forceinline__ float2 c_two_minus(float2 a, float2 t)                 { float2 f; f.x = a.x * 2.0f - t.x; f.y = a.y * 2.0f - t.y; return f; }

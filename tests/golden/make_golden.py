@@ -127,6 +127,44 @@ def main():
             cc = ccuts if len(modes) > 3 else ccuts[:4]
             chan[f"{name}_chain_{''.join(map(str, modes))}"] = ref_chain(modes, x, cc)
     np.savez_compressed(os.path.join(HERE, "chan_golden.npz"), **chan)
+    # ------------------------------------------------------------------ float back-end (strict-IEEE scalar build of the reference)
+    f32 = C.c_float
+    ref.ref_backend_new.restype = vp; ref.ref_backend_new.argtypes = [f32, f32, f32, C.c_int, f32, f32]
+    ref.ref_backend_free.argtypes = [vp]
+    ref.ref_backend_feed.restype = i64; ref.ref_backend_feed.argtypes = [vp, vp, i64, vp]
+    ref.ref_fftfilt_new.restype = vp; ref.ref_fftfilt_new.argtypes = [f32, f32, C.c_int]
+    ref.ref_fftfilt_run.restype = i64; ref.ref_fftfilt_run.argtypes = [vp, C.c_int, vp, i64, vp]
+    ref.ref_gfft.argtypes = [vp, C.c_int, C.c_int]
+    ref.ref_discri.argtypes = [C.c_int, f32, vp, i64, vp]
+    ref.ref_nco_table.argtypes = [vp]
+    fl = {}
+    t = np.zeros(4096, np.float32); ref.ref_nco_table(t.ctypes.data); fl["nco_table"] = t
+    xin = synth.mix(6000, 31, 12000, 6000, 1)
+    for name, (nf, ir, orr, cut, tpp) in {"nfm": (-4567.0, 60000.0, 48000.0, 12500 / 2.2, 4.5), "ssb": (20000.0, 120000.0, 48000.0, 5000.0, 2.0)}.items():
+        h = ref.ref_backend_new(nf, ir, orr, 16, cut, tpp)
+        o = np.zeros(2 * 6000 + 8, np.float32); k = 0
+        for a, b in ((0, 1234), (1234, 1235), (1235, 6000)):
+            seg = np.ascontiguousarray(xin[2 * a: 2 * b])
+            k += ref.ref_backend_feed(h, seg.ctypes.data, b - a, o[2 * k:].ctypes.data)
+        ref.ref_backend_free(h)
+        fl[f"resamp_{name}"] = o[: 2 * k].copy()
+    # g_fft on an integer-valued vector, forward and inverse
+    v = synth.noise_iq(1024, 32, 30000).astype(np.float32)
+    a = v.copy(); ref.ref_gfft(a.ctypes.data, 1024, 0); fl["gfft1024_fwd"] = a
+    a = v.copy(); ref.ref_gfft(a.ctypes.data, 1024, 1); fl["gfft1024_inv"] = a
+    # fftfilt on the NFM-resampled stream, all run modes, + discriminators on the usb output
+    xr = fl["resamp_nfm"]
+    for mode, nm in ((0, "filt"), (1, "usb"), (2, "lsb")):
+        h = ref.ref_fftfilt_new(300 / 48000, 3000 / 48000, 1024)
+        o = np.zeros(xr.size + 2048, np.float32)
+        k = ref.ref_fftfilt_run(h, mode, xr.ctypes.data, xr.size // 2, o.ctypes.data)
+        fl[f"fftfilt_{nm}"] = o[: 2 * k].copy()
+    y = fl["fftfilt_usb"]
+    for kind, nm in ((0, "delta"), (1, "atan2")):
+        o = np.zeros(y.size // 2, np.float32)
+        ref.ref_discri(kind, 24.0, y.ctypes.data, y.size // 2, o.ctypes.data)
+        fl[f"discri_{nm}"] = o
+    np.savez_compressed(os.path.join(HERE, "float_golden.npz"), **fl)
     print("golden written:", sorted(os.listdir(HERE)))
 
 

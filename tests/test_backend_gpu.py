@@ -97,3 +97,34 @@ def test_zero_and_constant_input():
     k = np.empty(2 * 5000, np.int16); k[0::2] = 32767; k[1::2] = -32768
     bank.feed([k])
     assert ulp_diff(bank.read(0), o.feed(k)) == 0
+
+
+def test_cfg4_pipeline_bank_to_backend_on_device():
+    """SURVEY cfg 4 shape at small scale: DownChannelizer bank -> (device hand-over) -> NCO -> Interpolator ->
+    fftfilt SSB -> NFM discriminator, 16 channels, against oracle chain + oracle back-end per channel."""
+    fs = 61_440_000
+    n_ch = 16
+    k = np.arange(n_ch)
+    fcs = [int(v) for v in (-25_000_000 + k * (50_000_000 / 15) + 137 * k)]
+    bank = sa.ChannelizerBank(fs, [48000] * n_ch, fcs)
+    cfgs, oras, chains = [], [], []
+    for c in range(n_ch):
+        modes, out_rate, ofs = bank.info(c)
+        cfg = dict(in_rate=out_rate, nco_freq=-ofs, out_rate=48000, interp_cutoff=12500 / 2.2, taps_per_phase=4.5,
+                   filt_mode=2, f1=300 / 48000, f2=5000 / 48000, discri=1, fm_scaling=48000 / 2000)
+        g, o = mk(cfg)
+        cfgs.append(g); oras.append(o); chains.append(orc.Chain(modes))
+    be = sa.BackendBank(cfgs)
+    x = synth.mix(3_000_000, 77, 3000, 1500, 1)
+    for a, b in ((0, 1_000_001), (1_000_001, 3_000_000)):
+        seg = x[2 * a: 2 * b]
+        bank.feed(seg)
+        ptrs, cnts = zip(*[bank.last_dev(c) for c in range(n_ch)])
+        bank.sync()
+        be.feed_dev(ptrs, cnts)
+        for c in range(n_ch):
+            want = oras[c].feed(chains[c].feed(seg))
+            got = be.read(c)
+            assert got.size == want.size, (c, got.size, want.size)
+            assert ulp_diff(got, want) == 0, c
+            bank.skip(c)

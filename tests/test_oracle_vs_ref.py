@@ -60,3 +60,43 @@ def test_chains_random(ref):
             k = ref.ref_chain_feed(h, seg.ctypes.data, b - a, out.ctypes.data)
             assert np.array_equal(o.feed(seg), out[: 2 * k]), (trial, list(modes))
         ref.ref_chain_free(h)
+
+
+def test_float_backend_vs_reference():
+    """NCO + Interpolator, g_fft, fftfilt (with its filter design), discriminators: oracle == reference, bit for bit"""
+    L = C.CDLL(REF)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    L.ref_backend_new.restype = vp; L.ref_backend_new.argtypes = [f32, f32, f32, C.c_int, f32, f32]
+    L.ref_backend_feed.restype = i64; L.ref_backend_feed.argtypes = [vp, vp, i64, vp]
+    L.ref_fftfilt_new.restype = vp; L.ref_fftfilt_new.argtypes = [f32, f32, C.c_int]
+    L.ref_fftfilt_run.restype = i64; L.ref_fftfilt_run.argtypes = [vp, C.c_int, vp, i64, vp]
+    L.ref_gfft.argtypes = [vp, C.c_int, C.c_int]
+    L.ref_discri.argtypes = [C.c_int, f32, vp, i64, vp]
+    O = orc.lib(); orc._sig_float(O)
+    rng = np.random.default_rng(9)
+    for n in (16, 128, 1024, 8192):
+        for inv in (0, 1):
+            x = (rng.standard_normal(2 * n) * 1000).astype(np.float32)
+            a, b = x.copy(), x.copy()
+            L.ref_gfft(a.ctypes.data, n, inv); O.sdro_gfft(b.ctypes.data, n, inv)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (n, inv)
+    for nf, ir, orr, cut, tpp in [(-4567.0, 60000.0, 48000.0, 12500 / 2.2, 4.5), (20000.0, 120000.0, 48000.0, 5000.0, 2.0), (0.0, 48000.0, 48000.0, 3000.0, 4.5)]:
+        n = 30000
+        x = synth.noise_iq(n, 55, 30000)
+        hr = L.ref_backend_new(nf, ir, orr, 16, cut, tpp); o = orc.Backend(ir, nf, orr, cut, tpp)
+        A = np.zeros(2 * n + 8, np.float32)
+        k = L.ref_backend_feed(hr, x.ctypes.data, n, A.ctypes.data)
+        assert np.array_equal(A[: 2 * k].view(np.uint32), o.feed(x).view(np.uint32))
+    for f1, f2 in [(300 / 48000, 3000 / 48000), (0.0, 5000 / 48000), (0.05, 0.02)]:
+        for mode in (0, 1, 2):
+            n = 4000
+            x = (rng.standard_normal(2 * n) * 3000).astype(np.float32)
+            hr = L.ref_fftfilt_new(f1, f2, 1024); ho = O.sdro_fftfilt_new(f1, f2, 1024)
+            A = np.zeros(2 * n + 8, np.float32); B = np.zeros(2 * n + 8, np.float32)
+            ka = L.ref_fftfilt_run(hr, mode, x.ctypes.data, n, A.ctypes.data); kb = O.sdro_fftfilt_run(ho, mode, x.ctypes.data, n, B.ctypes.data)
+            assert ka == kb and np.array_equal(A[: 2 * ka].view(np.uint32), B[: 2 * kb].view(np.uint32)), (f1, f2, mode)
+    x = (rng.standard_normal(20000) * 1000).astype(np.float32); x[:10] = 0
+    for kind in (0, 1):
+        A = np.zeros(10000, np.float32); B = np.zeros(10000, np.float32)
+        L.ref_discri(kind, 24.0, x.ctypes.data, 10000, A.ctypes.data); O.sdro_discri(kind, 24.0, x.ctypes.data, 10000, B.ctypes.data)
+        assert np.array_equal(A.view(np.uint32), B.view(np.uint32)), kind
