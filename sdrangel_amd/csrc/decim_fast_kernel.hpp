@@ -167,7 +167,10 @@ __device__ __forceinline__ void stage_i32_split(const int* __restrict__ oI, cons
 __host__ __device__ constexpr bool df_in16(int s) { return s <= 3; }          // stage s reads packed int16 arms
 __host__ __device__ constexpr int df_arr(int s)
 {
-    return df_in16(s) ? (HIST / 2 + (DF_SUB >> (s + 1))) : (HIST + (DF_SUB >> s));
+    // int32 (tail) arrays are only ever touched with 4-byte accesses by lanes that alternate between the I and
+    // the Q array: an ODD array pitch puts the two on opposite bank parities (SQ_LDS_BANK_CONFLICT was 24 % of
+    // the LDS cycles with the natural 96/64/48-dword pitches, all multiples of 16 banks)
+    return df_in16(s) ? (HIST / 2 + (DF_SUB >> (s + 1))) : (HIST + (DF_SUB >> s) + 1);
 }
 __host__ __device__ constexpr int df_off(int s) { int o = 0; for (int u = 1; u < s; u++) o += 4 * df_arr(u); return o; }
 __host__ __device__ constexpr int df_lds_dwords(int L) { return df_off(L + 1); }
@@ -285,7 +288,7 @@ void decim_fast_kernel(const uint4* __restrict__ hist,     // DF_CHUNK samples: 
         static_for<1, L + 1>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             constexpr int HD = df_in16(s) ? HIST / 2 : HIST;
-            constexpr int ND = df_arr(s) - HD;
+            constexpr int ND = df_in16(s) ? (DF_SUB >> (s + 1)) : (DF_SUB >> s);      // payload dwords per array
             uint32_t* a = lds + df_off(s);
             // 4 arrays x HD dwords; read everything first (the regions overlap when ND < HD)
             constexpr int TOT = 4 * HD, PER = (TOT + 63) / 64;
