@@ -56,8 +56,16 @@ __device__ __forceinline__ void stage_pk16(const uint32_t* __restrict__ oI, cons
 #pragma unroll
         for (int q = 0; q < NW; q++) { wI[q] = oI[b + q]; wQ[q] = oQ[b + q]; }
     }
+    if constexpr (R == 8) { ld_centre5<EB>(eI + b, vI); ld_centre5<EB>(eQ + b, vQ); }
+    else if constexpr (R == 4 && EB % 2 == 0) {
+        // b = 2t: 8-byte aligned; three dwords as b64 + b32
+        const uint2 a = *reinterpret_cast<const uint2*>(eI + b + EB), c = *reinterpret_cast<const uint2*>(eQ + b + EB);
+        vI[0] = a.x; vI[1] = a.y; vI[2] = eI[b + EB + 2];
+        vQ[0] = c.x; vQ[1] = c.y; vQ[2] = eQ[b + EB + 2];
+    } else {
 #pragma unroll
-    for (int q = 0; q < NE; q++) { vI[q] = eI[b + EB + q]; vQ[q] = eQ[b + EB + q]; }
+        for (int q = 0; q < NE; q++) { vI[q] = eI[b + EB + q]; vQ[q] = eQ[b + EB + q]; }
+    }
 
     static_for<0, R>([&](auto rc) {
         constexpr int r = decltype(rc)::value;

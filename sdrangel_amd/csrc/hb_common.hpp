@@ -83,6 +83,21 @@ template<int ORDER, int MODE> __host__ __device__ constexpr uint32_t pk_coef(int
     return pk16(lo, hi);
 }
 
+// five centre-tap dwords p[EB .. EB+4] of a lane whose p is 16-byte aligned (p = arm + 4t): as wide aligned
+// reads -- five separate ds_read_b32 with a lane stride of 16 bytes are 4-way bank conflicts each
+template<int EB>
+__device__ __forceinline__ void ld_centre5(const uint32_t* __restrict__ p, uint32_t (&v)[5])
+{
+    if constexpr (EB % 4 == 0) {
+        const uint4 a = *reinterpret_cast<const uint4*>(p + EB);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = p[EB + 4];
+    } else {
+        static_assert(EB % 4 == 2, "centre window starts on an 8-byte boundary");
+        const uint4 a = *reinterpret_cast<const uint4*>(p + EB - 2), b = *reinterpret_cast<const uint4*>(p + EB + 2);
+        v[0] = a.z; v[1] = a.w; v[2] = b.x; v[3] = b.y; v[4] = b.z;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Stage on PACKED int16 arms (two int16 per dword).  Used where the stage input is int16 by
 // construction: stage 1 of every Decimators chain (raw samples; the `<< pre` of
@@ -115,8 +130,8 @@ __device__ __forceinline__ void stage_pk16_r8(const uint32_t* __restrict__ oI, c
     // is the HIGH half of dword EB and output r uses int16 offset r+1 of a 5-dword window.
     constexpr int EB = (32 - CD - 1) / 2;
     uint32_t vI[5], vQ[5];
-#pragma unroll
-    for (int q = 0; q < 5; q++) { vI[q] = eI[4 * t + EB + q]; vQ[q] = eQ[4 * t + EB + q]; }
+    ld_centre5<EB>(eI + 4 * t, vI);
+    ld_centre5<EB>(eQ + 4 * t, vQ);
 
     static_for<0, 8>([&](auto rc) {
         constexpr int r = decltype(rc)::value;

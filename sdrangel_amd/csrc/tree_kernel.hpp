@@ -162,8 +162,8 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                     }
                     constexpr int EB = (32 - (hb_pairs<48>() - 1) - 1) / 2;      // 10
                     uint32_t vI[5], vQ[5];
-#pragma unroll
-                    for (int q = 0; q < 5; q++) { vI[q] = cI[4 * t + EB + q]; vQ[q] = cQ[4 * t + EB + q]; }
+                    ld_centre5<EB>(cI + 4 * t, vI);
+                    ld_centre5<EB>(cQ + 4 * t, vQ);
                     static_for<0, 8>([&](auto rc) {
                         constexpr int r = decltype(rc)::value;
                         int aI = 0, aQ = 0;
