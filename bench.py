@@ -86,7 +86,7 @@ def cpu_baseline(sample_cplx: int, reps: int, log2: int = 6):
                       f"one independent stream per thread ({n_thr} threads); single_thread_MSps = 1 thread, as sdrangelbench runs it"}
 
 
-def load_traffic(kernel: str, batch: int):
+def load_traffic(kernel: str, batch: int, workload: str):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/*traffic*.json), or None."""
     import glob
     best = None
@@ -96,8 +96,8 @@ def load_traffic(kernel: str, batch: int):
         except Exception:
             continue
         for e in d.get("kernels", []):
-            if e.get("kernel", "").startswith(kernel.split("<")[0]) and e.get("batch_cplx") == batch and kernel in e.get("kernel", ""):
-                best = e.get("hbm_bytes_per_launch")
+            if e.get("workload") == workload and e.get("batch_cplx") == batch and e.get("kernel", "").startswith(kernel.split("<")[0]):
+                best = e.get("hbm_bytes_per_step", e.get("hbm_bytes_per_launch"))
     return best
 
 
@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="decim64", choices=["decim64", "chan32"])
+    ap.add_argument("--workload", default="decim64", choices=["decim64", "chan32", "chan128", "cfg4"])
     ap.add_argument("--batch", type=int, default=256 * 1024 * 1024, help="complex samples per step per GPU (1 GiB of int16 I/Q)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
@@ -143,16 +143,37 @@ def main():
         bytes_per_sample = 4.0 + 4.0 / 64
         workload = f"cfg2: decimate64_cen Decimators<qint32,qint16,16,12>, one stream per GPU, {B} complex int16 samples per step, device-resident"
     else:
-        k = torch.arange(32, dtype=torch.float64)
-        fcs = (-15_000_000 + k * (30_000_000 / 31) + 137 * k).to(torch.int64).tolist()
-        h = sa.ChannelizerBank(61_440_000, [48000] * 32, fcs, device=dev.index)
+        # cfg 3 = 32 channels, cfg 5 = 128 channels per stream/GPU, cfg 4 = 256 channels + demod front
+        n_ch = {"chan32": 32, "chan128": 128, "cfg4": 256}[args.workload]
+        k = torch.arange(n_ch, dtype=torch.float64)
+        if args.workload == "cfg4":
+            fcs = (-25_000_000 + k * (50_000_000 / 255)).to(torch.int64).tolist()
+        else:
+            fcs = (-15_000_000 + k * (30_000_000 / (n_ch - 1)) + 137 * k).to(torch.int64).tolist()
+        h = sa.ChannelizerBank(61_440_000, [48000] * n_ch, fcs, device=dev.index)
         h.set_stream(stream)
+        be = None
+        if args.workload == "cfg4":
+            cfgs = []
+            for c in range(n_ch):
+                _m, out_rate, ofs = h.info(c)
+                cfgs.append(sa.BackendCfg(in_rate=out_rate, nco_freq=-ofs, out_rate=48000, interp_cutoff=12500 / 2.2, taps_per_phase=4.5,
+                                          filt_mode=2, f1=300 / 48000, f2=5000 / 48000, discri=1, fm_scaling=48000 / 2000))
+            be = sa.BackendBank(cfgs, device=dev.index)
         def step():
             h.feed_dev(x.data_ptr(), B)
-            for c in range(32):                 # consumer side: drop the queued outputs (host bookkeeping only)
+            if be is not None:
+                ptrs, cnts = zip(*[h.last_dev(c) for c in range(n_ch)])
+                h.sync()                         # the back-end runs on its own stream
+                be.feed_dev(ptrs, cnts)
+                be.sync()
+            for c in range(n_ch):               # consumer side: drop the queued outputs (host bookkeeping only)
                 h.skip(c)
-        bytes_per_sample = 4.0 + 32 * 4.0 / 1024
-        workload = f"cfg3: DownChannelizer bank, 32 channels (48 kS/s each) from one 61.44 MS/s-shaped stream per GPU, {B} samples per step"
+        depth = sum(4.0 / (1 << len(h.info(c)[0])) for c in range(n_ch))
+        bytes_per_sample = 4.0 + depth + (n_ch * 4.0 * 48000 / 61_440_000 if be is not None else 0.0)
+        workload = (f"{args.workload}: DownChannelizer bank, {n_ch} channels (48 kS/s each) from one 61.44 MS/s-shaped stream per GPU"
+                    + (" + NCO/Interpolator/fftfilt-SSB/NFM-discriminator front per channel" if be is not None else "")
+                    + f", {B} samples per step")
 
     for _ in range(args.warmup):
         step()
@@ -175,7 +196,7 @@ def main():
             "config": {"workload": workload, "streams": n_gpus, "parallelism": f"{n_gpus} independent stream(s), one per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": load_traffic(ll["kernel"], B),
+                         "traffic": load_traffic(ll["kernel"], B, args.workload),
                          "kernel": ll["kernel"], "kernel_ms": round(kern_ms, 4), "launches": k_n,
                          "algorithmic_bytes_per_sample": bytes_per_sample,
                          "grid": ll["grid"], "block": ll["block"], "lds_bytes": ll["lds_bytes"]},

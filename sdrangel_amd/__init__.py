@@ -333,6 +333,9 @@ class BackendBank:
             raise SdrxError(f"sdrx_backend_read rc={n}: {lib().sdrx_last_error().decode()}")
         return out[:n].copy()
 
+    def sync(self):
+        _check(lib().sdrx_backend_sync(self._h), "sdrx_backend_sync")
+
     def design(self, ch: int):
         nt, inc = C.c_int32(), C.c_int32()
         taps = np.zeros(16 * 256, np.float32)

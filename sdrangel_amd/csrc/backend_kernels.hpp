@@ -39,8 +39,8 @@ struct BeChan {                         // device resident: config + carried sta
     float distance;
     int pending;                        // resampled samples waiting for a full fftfilt block
     float prev_arg, m1r, m1i;
-    // --- per feed (set by the host / by the kernels)
-    int n_in;                           // new input samples of this feed
+    // --- per feed (written by the kernels)
+    int n_in;                           // new input samples of this feed            (copied from BeBufs by be_schedule)
     int n_res;                          // resampler outputs of this feed            (written by be_schedule)
     int n_blocks;                       // complete fftfilt blocks of this feed       (written by be_schedule)
     int n_out;                          // samples in the output buffer after this feed
@@ -52,31 +52,49 @@ struct BeBufs {                         // per channel device pointers (per feed
     uint32_t* hist;                     // BE_HIST packed Samples: tail of the previous feeds
     uint32_t* hist_next;
     float2* mixed;                      // BE_HIST + n_in: NCO-mixed samples, index BE_HIST + k
-    uint32_t* sched;                    // per resampler output: k * 16 + phase
+    uint32_t* sched;                    // per resampler output o: sched[o * sched_stride] = k * 16 + phase (channel-interleaved
+                                        // so that the serial schedule lanes of a wave store to neighbouring addresses)
     float2* res;                        // [pending | new resampler outputs]
     float2* head;                       // n_blocks * 512
     float2* tail;                       // (1 + n_blocks) * 512; slot 0 = ovlbuf carried from the previous feed
     float2* cplx_out;                   // output when the last stage is complex (resampler or fftfilt)
     float* real_out;                    // output when a discriminator is enabled
+    long n_in;                          // new input samples of this feed (host -> device with the pointers, one copy)
+    long sched_stride;                  // = number of channels
 };
 
-// ---- 1. schedule: the float `distance` recurrence, one lane per channel (serial by nature)
+// ---- 1. schedule: the float `distance` recurrence, one lane per channel (serial by nature).
+// Walks emission by emission instead of input by input: while d >= 1 the reference's `d -= 1.0` is exact, so
+// after an emission leaves d_new the next one happens m = max(1, floor(d_new)) inputs later with
+// d = d_new - m (exact) -- or fl(d_new - 1) when d_new < 1 -- which is bit-for-bit what the per-input loop holds.
 __global__ void be_schedule_kernel(BeChan* __restrict__ ch, const BeBufs* __restrict__ bufs, int n_ch)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_ch) return;
     BeChan& s = ch[c];
     uint32_t* sched = bufs[c].sched;
-    float d = s.distance;
+    const long stride = bufs[c].sched_stride;
+    const int n_in = (int)bufs[c].n_in;
+    s.n_in = n_in;
+    float d = s.distance;                                   // value BEFORE the next input's `-= 1.0`
     const float step = s.step, ps = (float)s.phase_steps;
     int cnt = 0;
-    for (int k = 0; k < s.n_in; k++) {
-        d = d - 1.0f;                                       // *distance -= 1.0
-        if (d >= 1.0f) continue;
+    long k = -1;                                            // index of the last consumed input
+    for (;;) {
+        // inputs until the next emission
+        const int m = d >= 1.0f ? (int)floorf(d) : 1;
+        if (k + m >= n_in) {                                // the feed ends first: consume what is left, no emission
+            const int left = (int)(n_in - 1 - k);           // inputs still to consume (each: d -= 1, all stay >= 1 or it would emit)
+            d = d - (float)left;                            // exact: d - left >= 1 unless left == 0
+            break;
+        }
+        k += m;
+        d = d >= 1.0f ? d - (float)m : d - 1.0f;
         int ph = (int)floorf(d * ps);
         if (ph < 0) ph = 0;
-        sched[cnt++] = (uint32_t)k * 16u + (uint32_t)ph;
-        d = d + step;                                       // caller: m_interpolatorDistanceRemain += m_interpolatorDistance
+        sched[(long)cnt * stride] = (uint32_t)k * 16u + (uint32_t)ph;
+        cnt++;
+        d = d + step;
     }
     s.distance = d;
     s.n_res = cnt;
@@ -111,7 +129,7 @@ __global__ void be_fir_kernel(const BeChan* __restrict__ ch, const BeBufs* __res
     const BeBufs b = bufs[c];
     const bool direct = s.filt_mode == 0 && s.discri == 0;
     for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < s.n_res; o += gridDim.x * blockDim.x) {
-        const uint32_t e = b.sched[o];
+        const uint32_t e = b.sched[(long)o * b.sched_stride];
         const int k = (int)(e >> 4), ph = (int)(e & 15u);
         const float* t = taps + s.taps_off + ph * s.ntaps;
         const float2* x = b.mixed + BE_HIST + k;

@@ -61,7 +61,7 @@ float blackman(int i, int len)
 
 struct ChanHost {
     sdrx_backend_cfg cfg;
-    DevBuf mixed, sched, res, head, tail, cplx_out, real_out;
+    DevBuf mixed, res, head, tail, cplx_out, real_out;
     uint32_t* hist[2] = { nullptr, nullptr };
     int cur = 0;
     int64_t cap_in = 0;
@@ -78,7 +78,10 @@ struct sdrx_backend {
     std::vector<BeChan> h_chan;   // host mirror of the config part (state lives on the device)
     BeChan* d_chan = nullptr;
     BeBufs* d_bufs = nullptr;
-    std::vector<BeBufs> h_bufs;
+    DevBuf sched;                 // bank-wide, channel-interleaved: entry o of channel c at [o * n_ch + c]
+    int64_t sched_cap = 0;        // entries per channel
+    BeBufs* h_bufs = nullptr;     // pinned: the per-feed table goes to the device in one async copy
+    hipEvent_t bufs_ev = nullptr; // recorded behind that copy; waited on before the table is rewritten
     float* d_nco = nullptr; float* d_taps = nullptr; float2* d_filters = nullptr; float* d_utbl = nullptr;
     std::vector<float> taps_all; std::vector<float> filters_all;     // kept for inspection (tests)
     std::vector<int> taps_off, filt_off, ntaps;
@@ -108,7 +111,6 @@ static int ensure_capacity(sdrx_backend* b, int c, int64_t n_in)
     };
     int rc;
     if ((rc = grow_keep(h.mixed, (size_t)(BE_HIST + cap) * 8, 0))) return rc;
-    if ((rc = grow_keep(h.sched, n_res_max * 4, 0))) return rc;
     if ((rc = grow_keep(h.res, n_res_max * 8, (BE_FFT / 2) * 8))) return rc;
     if ((rc = grow_keep(h.head, n_blk_max * (BE_FFT / 2) * 8, 0))) return rc;
     if ((rc = grow_keep(h.tail, (n_blk_max + 1) * (BE_FFT / 2) * 8, (BE_FFT / 2) * 8))) return rc;
@@ -126,12 +128,15 @@ int sdrx_backend_destroy(sdrx_backend_t* b)
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (auto& h : b->ch) {
-        h.mixed.release(); h.sched.release(); h.res.release(); h.head.release(); h.tail.release();
+        h.mixed.release(); h.res.release(); h.head.release(); h.tail.release();
         h.cplx_out.release(); h.real_out.release(); h.stage_in.release();
         for (int i = 0; i < 2; i++) if (h.hist[i]) (void)hipFree(h.hist[i]);
     }
+    b->sched.release();
     if (b->d_chan) (void)hipFree(b->d_chan);
     if (b->d_bufs) (void)hipFree(b->d_bufs);
+    if (b->h_bufs) (void)hipHostFree(b->h_bufs);
+    if (b->bufs_ev) (void)hipEventDestroy(b->bufs_ev);
     if (b->d_nco) (void)hipFree(b->d_nco);
     if (b->d_taps) (void)hipFree(b->d_taps);
     if (b->d_filters) (void)hipFree(b->d_filters);
@@ -162,7 +167,7 @@ int sdrx_backend_create(sdrx_backend_t** out, int device, int32_t n_ch, const sd
     hipError_t e = hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete b; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
     b->stream = b->own_stream;
-    b->ch.resize((size_t)n_ch); b->h_chan.resize((size_t)n_ch); b->h_bufs.resize((size_t)n_ch);
+    b->ch.resize((size_t)n_ch); b->h_chan.resize((size_t)n_ch);
     b->taps_off.resize((size_t)n_ch); b->filt_off.resize((size_t)n_ch); b->ntaps.resize((size_t)n_ch);
 
 #define BE_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int r_ = hip_fail(e_, #call, __FILE__, __LINE__); sdrx_backend_destroy(b); return r_; } } while (0)
@@ -231,6 +236,9 @@ int sdrx_backend_create(sdrx_backend_t** out, int device, int32_t n_ch, const sd
     BE_TRY(hipMemcpy(b->d_taps, b->taps_all.data(), b->taps_all.size() * 4, hipMemcpyHostToDevice));
     BE_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_chan), (size_t)n_ch * sizeof(BeChan)));
     BE_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_bufs), (size_t)n_ch * sizeof(BeBufs)));
+    BE_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_bufs), (size_t)n_ch * sizeof(BeBufs), hipHostMallocDefault));
+    BE_TRY(hipEventCreateWithFlags(&b->bufs_ev, hipEventDisableTiming));
+    BE_TRY(hipEventRecord(b->bufs_ev, b->stream));
     BE_TRY(hipMemcpy(b->d_chan, b->h_chan.data(), (size_t)n_ch * sizeof(BeChan), hipMemcpyHostToDevice));
 #undef BE_TRY
     *out = b;
@@ -241,26 +249,31 @@ static int feed_common(sdrx_backend* b, const int16_t* const* d_iq, const int64_
 {
     int64_t n_max = 0;
     for (int c = 0; c < b->n_ch; c++) {
-        if (n_per_ch[c] < 0 || n_per_ch[c] > 0x3fffffff) { set_error("sdrx_backend_feed: bad length"); return SDRX_EINVAL; }
+        if (n_per_ch[c] < 0 || n_per_ch[c] > 0x0fffffff) { set_error("sdrx_backend_feed: bad length"); return SDRX_EINVAL; }
         int rc = ensure_capacity(b, c, std::max<int64_t>(n_per_ch[c], 1)); if (rc) return rc;
         n_max = std::max(n_max, n_per_ch[c]);
     }
-    // per-feed fields: n_in goes into the device-side BeChan (the rest of it is state we must not touch)
-    std::vector<int> n_in((size_t)b->n_ch);
+    if (n_max + 1024 > b->sched_cap) {
+        int64_t cap = b->sched_cap ? b->sched_cap : 8192;
+        while (cap < n_max + 1024) cap *= 2;
+        SDRX_HIP(hipStreamSynchronize(b->stream));
+        int rc = b->sched.reserve((size_t)cap * (size_t)b->n_ch * 4); if (rc) return rc;
+        b->sched_cap = cap;
+    }
+    // per-feed table (pointers + n_in), pinned, one async copy
+    SDRX_HIP(hipEventSynchronize(b->bufs_ev));            // previous feed's copy has read the table
     for (int c = 0; c < b->n_ch; c++) {
         ChanHost& h = b->ch[(size_t)c];
-        BeBufs& u = b->h_bufs[(size_t)c];
+        BeBufs& u = b->h_bufs[c];
         u.in = reinterpret_cast<const uint32_t*>(d_iq[c]);
         u.hist = h.hist[h.cur]; u.hist_next = h.hist[h.cur ^ 1];
-        u.mixed = static_cast<float2*>(h.mixed.p); u.sched = static_cast<uint32_t*>(h.sched.p);
+        u.mixed = static_cast<float2*>(h.mixed.p); u.sched = static_cast<uint32_t*>(b->sched.p) + c; u.sched_stride = b->n_ch;
         u.res = static_cast<float2*>(h.res.p); u.head = static_cast<float2*>(h.head.p); u.tail = static_cast<float2*>(h.tail.p);
         u.cplx_out = static_cast<float2*>(h.cplx_out.p); u.real_out = static_cast<float*>(h.real_out.p);
-        n_in[(size_t)c] = (int)n_per_ch[c];
-        SDRX_HIP(hipMemcpyAsync(reinterpret_cast<char*>(b->d_chan + c) + offsetof(BeChan, n_in), &n_in[(size_t)c], 4,
-                                hipMemcpyHostToDevice, b->stream));
+        u.n_in = n_per_ch[c];
     }
-    SDRX_HIP(hipMemcpyAsync(b->d_bufs, b->h_bufs.data(), (size_t)b->n_ch * sizeof(BeBufs), hipMemcpyHostToDevice, b->stream));
-    SDRX_HIP(hipStreamSynchronize(b->stream));            // n_in / h_bufs are stack/host vectors: copies must be done before we return
+    SDRX_HIP(hipMemcpyAsync(b->d_bufs, b->h_bufs, (size_t)b->n_ch * sizeof(BeBufs), hipMemcpyHostToDevice, b->stream));
+    SDRX_HIP(hipEventRecord(b->bufs_ev, b->stream));
     const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, (n_max + BE_HIST + 255) / 256));
     hipLaunchKernelGGL(be_schedule_kernel, dim3((unsigned)((b->n_ch + 63) / 64)), dim3(64), 0, b->stream, b->d_chan, b->d_bufs, b->n_ch);
     SDRX_HIP(hipGetLastError());

@@ -108,3 +108,18 @@ def test_partial_reads_and_reconfigure():
     bank.reset()
     bank.feed(x[: 2 * 100_000])
     assert np.array_equal(bank.read(5), orc.Chain(ref[5][1]).feed(x[: 2 * 100_000]))
+
+
+def test_bank256_cfg4_shape_spot_check():
+    """256 channels (SURVEY cfg 4 spacing): planner splits the wide trie over several passes; check a spread of channels"""
+    n_ch = 256
+    k = np.arange(n_ch)
+    fcs = [int(v) for v in (-25_000_000 + k * (50_000_000 / 255))]
+    bank = sa.ChannelizerBank(FS, [48000] * n_ch, fcs)
+    x = orc.synth_iq(1 << 20, seed=33, amp=2047, tone=(0.07, 700))
+    bank.feed(x[: 2 * 400_003]); bank.feed(x[2 * 400_003:])
+    for c in (0, 1, 17, 100, 127, 128, 200, 254, 255):
+        modes, out_rate, ofs = orc.chan_plan(FS, 48000, fcs[c])
+        m, r, o = bank.info(c)
+        assert np.array_equal(m, modes) and (r, o) == (out_rate, ofs)
+        assert np.array_equal(bank.read(c), orc.Chain(modes).feed(x)), c
