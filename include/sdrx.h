@@ -53,6 +53,13 @@ typedef struct sdrx_decim sdrx_decim_t;
 /* log2_decim 0..6, fcpos SDRX_FC_*, input_bits 8|12|16 (decimation_shifts<16,InputBits>,
  * decimators.h:25-185). */
 int sdrx_decim_create(sdrx_decim_t** out, int device, int log2_decim, int fcpos, int input_bits);
+/* DecimatorsU<qint32, quint8, 16, 8, Shift> (sdrbase/dsp/decimatorsu.h:175-216; RTL-SDR thread,
+ * plugins/samplesource/rtlsdr/rtlsdrthread.h:55 uses Shift = 127): unsigned 8-bit I/Q, value = byte - shift,
+ * decimation_shifts<16,8>.  Same cascades, strides and tail drop as Decimators. */
+int sdrx_decim_create_u8(sdrx_decim_t** out, int device, int log2_decim, int fcpos, int shift);
+int sdrx_decim_process_u8(sdrx_decim_t* h, const uint8_t* iq, int32_t n_uint8, int16_t* out_iq, int32_t* n_out_cplx);
+/* d_iq must be 8-byte aligned */
+int sdrx_decim_process_dev_u8(sdrx_decim_t* h, const uint8_t* d_iq, int64_t n_uint8, int16_t* d_out_iq, int64_t* n_out_cplx);
 int sdrx_decim_destroy(sdrx_decim_t* h);
 /* zero filter state == a freshly constructed Decimators object */
 int sdrx_decim_reset(sdrx_decim_t* h);

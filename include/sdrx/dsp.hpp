@@ -72,6 +72,40 @@ private:
     sdrx_decim_t* m_h[7][3];
 };
 
+// DecimatorsU<qint32, quint8, 16, 8, Shift> (dsp/decimatorsu.h:175-216), the RTL-SDR thread's member
+// (plugins/samplesource/rtlsdr/rtlsdrthread.h:55)
+template<typename StorageType, typename T, unsigned SdrBits, unsigned InputBits, int Shift>
+class DecimatorsU {
+    static_assert(sizeof(T) == 1 && SdrBits == 16 && InputBits == 8, "this build covers DecimatorsU<qint32,quint8,16,8,Shift>");
+public:
+    explicit DecimatorsU(int device = 0) : m_device(device) { for (auto& row : m_h) for (auto& h : row) h = nullptr; }
+    ~DecimatorsU() { for (auto& row : m_h) for (auto& h : row) if (h) sdrx_decim_destroy(h); }
+    DecimatorsU(const DecimatorsU&) = delete;
+    DecimatorsU& operator=(const DecimatorsU&) = delete;
+    void decimate1(SampleVector::iterator* it, const T* buf, int32_t len) { run(0, SDRX_FC_CEN, it, buf, len); }
+#define SDRX_DECIMU(K, L)                                                                                         \
+    void decimate##K##_inf(SampleVector::iterator* it, const T* buf, int32_t len) { run(L, SDRX_FC_INF, it, buf, len); } \
+    void decimate##K##_sup(SampleVector::iterator* it, const T* buf, int32_t len) { run(L, SDRX_FC_SUP, it, buf, len); } \
+    void decimate##K##_cen(SampleVector::iterator* it, const T* buf, int32_t len) { run(L, SDRX_FC_CEN, it, buf, len); }
+    SDRX_DECIMU(2, 1) SDRX_DECIMU(4, 2) SDRX_DECIMU(8, 3) SDRX_DECIMU(16, 4) SDRX_DECIMU(32, 5) SDRX_DECIMU(64, 6)
+#undef SDRX_DECIMU
+private:
+    void run(int log2, int fcpos, SampleVector::iterator* it, const T* buf, int32_t len)
+    {
+        sdrx_decim_t*& h = m_h[log2][fcpos];
+        if (!h && sdrx_decim_create_u8(&h, m_device, log2, fcpos, Shift) != SDRX_OK) {
+            std::fprintf(stderr, "sdrx::DecimatorsU: %s\n", sdrx_last_error()); h = nullptr; return;
+        }
+        int32_t n = 0;
+        if (sdrx_decim_process_u8(h, reinterpret_cast<const uint8_t*>(buf), len, reinterpret_cast<int16_t*>(&**it), &n) != SDRX_OK) {
+            std::fprintf(stderr, "sdrx::DecimatorsU: %s\n", sdrx_last_error()); return;
+        }
+        *it += n;
+    }
+    int m_device;
+    sdrx_decim_t* m_h[7][3];
+};
+
 // N DownChannelizers on one device stream.  configure() == DownChannelizer::configure(queue, rate, fc)
 // (downchannelizer.cpp:44-48) for one channel; feed() == the engine feeding every channel's
 // DownChannelizer::feed with the same span; pull() hands over what m_sampleSink->feed would have got.

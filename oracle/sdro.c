@@ -90,7 +90,7 @@ static inline int hb_push(hb_stage* s, int32_t* re, int32_t* im)
 
 /* ------------------------------------------------------------------ Decimators */
 struct sdro_decim {
-    int log2, fcpos, bits;
+    int log2, fcpos, bits, ushift;
     int pre, post, group;
     hb_stage st[6];
 };
@@ -151,6 +151,34 @@ int32_t sdro_decim_process(sdro_decim* d, const int16_t* iq, int32_t n_int16, in
     for (int32_t i = 0; i < n_cplx; i++) {
         int32_t re = (int32_t)((uint32_t)(int32_t)iq[2*i]   << d->pre);
         int32_t im = (int32_t)((uint32_t)(int32_t)iq[2*i+1] << d->pre);
+        int s = 0;
+        for (; s < d->log2; s++)
+            if (!hb_push(&d->st[s], &re, &im)) break;
+        if (s == d->log2) {
+            out[2*n_out]   = (int16_t)(re >> d->post);
+            out[2*n_out+1] = (int16_t)(im >> d->post);
+            n_out++;
+        }
+    }
+    return n_out;
+}
+
+/* DecimatorsU (decimatorsu.h:218-3251): same cascades and strides, input (buf[pos] - Shift) << pre */
+sdro_decim* sdro_decimu_new(int log2, int fcpos, int shift)
+{
+    sdro_decim* d = sdro_decim_new(log2, fcpos, 8);
+    if (d) d->ushift = shift;
+    return d;
+}
+
+int32_t sdro_decimu_process(sdro_decim* d, const uint8_t* iq, int32_t n_u8, int16_t* out)
+{
+    if (n_u8 < d->group) return 0;
+    const int32_t n_cplx = (n_u8 / d->group) * (d->group / 2);
+    int32_t n_out = 0;
+    for (int32_t i = 0; i < n_cplx; i++) {
+        int32_t re = (int32_t)((uint32_t)((int32_t)iq[2*i]   - d->ushift) << d->pre);
+        int32_t im = (int32_t)((uint32_t)((int32_t)iq[2*i+1] - d->ushift) << d->pre);
         int s = 0;
         for (; s < d->log2; s++)
             if (!hb_push(&d->st[s], &re, &im)) break;

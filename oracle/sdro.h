@@ -31,6 +31,9 @@ void        sdro_decim_reset(sdro_decim*);
 /* iq: interleaved int16 I,Q; n_int16 = number of int16 (the reference's `len`).  Whole groups
  * only, tail dropped (decimators.h:3492).  Returns #complex outputs written to out_iq. */
 int32_t     sdro_decim_process(sdro_decim*, const int16_t* iq, int32_t n_int16, int16_t* out_iq);
+/* DecimatorsU<qint32, quint8, 16, 8, Shift> (decimatorsu.h:175-216): unsigned 8-bit I/Q, value = buf - Shift */
+sdro_decim* sdro_decimu_new(int log2_decim, int fcpos, int shift);
+int32_t     sdro_decimu_process(sdro_decim*, const uint8_t* iq, int32_t n_uint8, int16_t* out_iq);
 /* #int16 consumed per loop iteration of the reference function (its `pos +=` stride). */
 int32_t     sdro_decim_group_int16(int log2_decim, int fcpos);
 

@@ -58,6 +58,9 @@ def lib() -> C.CDLL:
         "sdrx_last_error": (C.c_char_p, []),
         "sdrx_device_count": (C.c_int, []),
         "sdrx_decim_create": (C.c_int, [pp, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "sdrx_decim_create_u8": (C.c_int, [pp, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "sdrx_decim_process_u8": (C.c_int, [vp, vp, i32, vp, C.POINTER(i32)]),
+        "sdrx_decim_process_dev_u8": (C.c_int, [vp, vp, i64, vp, C.POINTER(i64)]),
         "sdrx_decim_destroy": (C.c_int, [vp]),
         "sdrx_decim_reset": (C.c_int, [vp]),
         "sdrx_decim_process": (C.c_int, [vp, vp, i32, vp, C.POINTER(i32)]),
@@ -200,6 +203,24 @@ class Decimators:
         g, b, l = C.c_int(), C.c_int(), C.c_int()
         _check(lib().sdrx_decim_last_launch(self._h, name, 128, C.byref(g), C.byref(b), C.byref(l)), "last_launch")
         return {"kernel": name.value.decode(), "grid": g.value, "block": b.value, "lds_bytes": l.value}
+
+
+class DecimatorsU(Decimators):
+    """DecimatorsU<qint32, quint8, 16, 8, shift> (sdrbase/dsp/decimatorsu.h): unsigned 8-bit I/Q (RTL-SDR)."""
+
+    def __init__(self, log2_decim: int, fcpos: int = FC_CEN, shift: int = 127, device: int = 0):
+        self._h = C.c_void_p()
+        _check(lib().sdrx_decim_create_u8(C.byref(self._h), device, log2_decim, fcpos, shift), "sdrx_decim_create_u8")
+        self.log2, self.fcpos, self.input_bits = log2_decim, fcpos, 8
+
+    def decimate(self, buf) -> np.ndarray:
+        buf = np.ascontiguousarray(buf)
+        if buf.dtype != np.uint8:
+            raise TypeError("expected uint8 I/Q")
+        out = np.empty(max(2 * ((buf.size // 2) >> self.log2), 2), np.int16)
+        n = C.c_int32()
+        _check(lib().sdrx_decim_process_u8(self._h, buf.ctypes.data, buf.size, out.ctypes.data, C.byref(n)), "sdrx_decim_process_u8")
+        return out[: 2 * n.value]
 
 
 def chan_plan(in_rate: int, req_rate: int, req_fc: int):

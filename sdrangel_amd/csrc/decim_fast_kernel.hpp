@@ -183,13 +183,16 @@ __host__ __device__ constexpr int df_arr(int s)
 __host__ __device__ constexpr int df_off(int s) { int o = 0; for (int u = 1; u < s; u++) o += 4 * df_arr(u); return o; }
 __host__ __device__ constexpr int df_lds_dwords(int L) { return df_off(L + 1); }
 
-template<int L, int FC, int PRE>
+template<int L, int FC, int PRE, bool U8>
 __global__ __launch_bounds__(64)
-void decim_fast_kernel(const uint4* __restrict__ hist,     // DF_CHUNK samples: tail of the previous call
-                       const uint4* __restrict__ in, uint32_t* __restrict__ out,
+void decim_fast_kernel(const void* __restrict__ hist_v,    // DF_CHUNK samples: tail of the previous call
+                       const void* __restrict__ in_v, uint32_t* __restrict__ out,
                        uint32_t* __restrict__ ovf_flags,   // one per DF_CHUNK-sample chunk of this call
-                       long n_in, int n_sub, int spw, int post)
+                       long n_in, int n_sub, int spw, int post, int in_shift)
 {
+    typedef typename Quad<U8>::T QT;
+    const QT* __restrict__ hist = static_cast<const QT*>(hist_v);
+    const QT* __restrict__ in = static_cast<const QT*>(in_v);
     constexpr int S = DF_SUB, LPT = S / 4 / 64;            // 4 uint4 per lane per sub-chunk
     __shared__ __attribute__((aligned(16))) uint32_t lds[df_lds_dwords(L)];
     const int lane = threadIdx.x;
@@ -200,13 +203,13 @@ void decim_fast_kernel(const uint4* __restrict__ hist,     // DF_CHUNK samples: 
 
     for (int i = lane; i < df_lds_dwords(L); i += 64) lds[i] = 0;
 
-    uint4 pre[LPT];
+    QT pre[LPT];
     auto fetch = [&](long sub) {
 #pragma unroll
         for (int j = 0; j < LPT; j++) {
-            const long g = sub * (S / 4) + j * 64 + lane;         // uint4 index; sub < 0: history
+            const long g = sub * (S / 4) + j * 64 + lane;         // quad index; sub < 0: history
             if (g < 0) pre[j] = hist[g + DF_CHUNK / 4];
-            else pre[j] = g < n_in4 ? in[g] : make_uint4(0, 0, 0, 0);
+            else pre[j] = g < n_in4 ? in[g] : Quad<U8>::zero();
         }
     };
     fetch(first - DF_WARM);
@@ -220,11 +223,7 @@ void decim_fast_kernel(const uint4* __restrict__ hist,     // DF_CHUNK samples: 
 #pragma unroll
             for (int j = 0; j < LPT; j++) {
                 const int q = HIST / 2 + j * 64 + lane;
-                const uint4 v = pre[j];
-                eI[q] = __builtin_amdgcn_perm(v.z, v.x, 0x05040100u);
-                eQ[q] = __builtin_amdgcn_perm(v.z, v.x, 0x07060302u);
-                oI[q] = __builtin_amdgcn_perm(v.w, v.y, 0x05040100u);
-                oQ[q] = __builtin_amdgcn_perm(v.w, v.y, 0x07060302u);
+                Quad<U8>::split(pre[j], in_shift, eI[q], eQ[q], oI[q], oQ[q]);
             }
         }
         if (sub + 1 < last) fetch(sub + 1);

@@ -59,14 +59,17 @@ __host__ __device__ constexpr int dc_mode(int L, int fc, int s)
     return other;
 }
 
-template<int L, int FC, int PRE>
+template<int L, int FC, int PRE, bool U8>
 __global__ __launch_bounds__(DC_THREADS, 3)
-void decim_chain_kernel(const uint4* __restrict__ hist,   // DC_CHUNK samples: tail of the previous call
-                        const uint4* __restrict__ in,     // n_in samples (16 B aligned)
+void decim_chain_kernel(const void* __restrict__ hist_v,  // DC_CHUNK samples: tail of the previous call
+                        const void* __restrict__ in_v,    // n_in samples (quad aligned)
                         uint32_t* __restrict__ out,       // n_in >> L packed Samples
                         const uint32_t* __restrict__ flags, // per chunk: recompute? (nullptr: all) -- set by the FAST kernel
-                        long n_in, int n_chunks, int cps, int post)
+                        long n_in, int n_chunks, int cps, int post, int in_shift)
 {
+    typedef typename Quad<U8>::T QT;
+    const QT* __restrict__ hist = static_cast<const QT*>(hist_v);
+    const QT* __restrict__ in = static_cast<const QT*>(in_v);
     constexpr int C = DC_CHUNK, NT = DC_THREADS;
     constexpr int LPT = C / 4 / NT;                       // uint4 loads per lane per chunk (4)
     __shared__ __attribute__((aligned(16))) uint32_t lds[dc_lds_dwords(L)];
@@ -89,15 +92,15 @@ void decim_chain_kernel(const uint4* __restrict__ hist,   // DC_CHUNK samples: t
 
     for (int i = tid; i < dc_lds_dwords(L); i += NT) lds[i] = 0;
 
-    uint4 pre[LPT];
+    QT pre[LPT];
     auto fetch = [&](long chunk) {
 #pragma unroll
         for (int j = 0; j < LPT; j++) {
-            const int q = j * NT + tid;                   // uint4 index inside the chunk
+            const int q = j * NT + tid;                   // quad index inside the chunk
             if (chunk < 0) pre[j] = hist[q];
             else {
                 const long g = chunk * (C / 4) + q;
-                pre[j] = g < n_in4 ? in[g] : make_uint4(0, 0, 0, 0);
+                pre[j] = g < n_in4 ? in[g] : Quad<U8>::zero();
             }
         }
     };
@@ -111,11 +114,7 @@ void decim_chain_kernel(const uint4* __restrict__ hist,   // DC_CHUNK samples: t
 #pragma unroll
             for (int j = 0; j < LPT; j++) {
                 const int q = HIST / 2 + j * NT + tid;
-                const uint4 v = pre[j];                   // (I0,Q0) (I1,Q1) (I2,Q2) (I3,Q3)
-                eI[q] = __builtin_amdgcn_perm(v.z, v.x, 0x05040100u);
-                eQ[q] = __builtin_amdgcn_perm(v.z, v.x, 0x07060302u);
-                oI[q] = __builtin_amdgcn_perm(v.w, v.y, 0x05040100u);
-                oQ[q] = __builtin_amdgcn_perm(v.w, v.y, 0x07060302u);
+                Quad<U8>::split(pre[j], in_shift, eI[q], eQ[q], oI[q], oQ[q]);   // (I0,Q0) (I1,Q1) (I2,Q2) (I3,Q3)
             }
         }
         if (chunk + 1 < last) fetch(chunk + 1);           // in flight during the whole chunk

@@ -83,6 +83,35 @@ template<int ORDER, int MODE> __host__ __device__ constexpr uint32_t pk_coef(int
     return pk16(lo, hi);
 }
 
+// ---- raw input quads: 4 consecutive complex samples as one vector load, de-interleaved into the four
+// packed-int16 polyphase dwords  eI=(I0,I2)  eQ=(Q0,Q2)  oI=(I1,I3)  oQ=(Q1,Q3)
+//   S16: the reference's Sample stream (int16 I,Q): 16 bytes per quad
+//   U8 : DecimatorsU input (quint8 I,Q, value = byte - Shift; decimatorsu.h:218-230): 8 bytes per quad
+template<bool U8> struct Quad;
+template<> struct Quad<false> {
+    typedef uint4 T;
+    static __device__ __forceinline__ T zero() { return make_uint4(0, 0, 0, 0); }
+    static __device__ __forceinline__ void split(const T v, int, uint32_t& eI, uint32_t& eQ, uint32_t& oI, uint32_t& oQ)
+    {
+        eI = __builtin_amdgcn_perm(v.z, v.x, 0x05040100u); eQ = __builtin_amdgcn_perm(v.z, v.x, 0x07060302u);
+        oI = __builtin_amdgcn_perm(v.w, v.y, 0x05040100u); oQ = __builtin_amdgcn_perm(v.w, v.y, 0x07060302u);
+    }
+};
+template<> struct Quad<true> {
+    typedef uint2 T;
+    // a zero SAMPLE is the byte `shift`; padding beyond the input only feeds outputs that are never stored
+    static __device__ __forceinline__ T zero() { return make_uint2(0, 0); }
+    static __device__ __forceinline__ void split(const T v, int shift, uint32_t& eI, uint32_t& eQ, uint32_t& oI, uint32_t& oQ)
+    {
+        // bytes of v.x: I0 Q0 I1 Q1, of v.y: I2 Q2 I3 Q3; selector 0x0c yields a zero byte (zero extension)
+        typedef short v2 __attribute__((ext_vector_type(2)));
+        const v2 sh = { (short)shift, (short)shift };
+        auto sub = [&](uint32_t x) { return __builtin_bit_cast(uint32_t, (v2)(__builtin_bit_cast(v2, x) - sh)); };
+        eI = sub(__builtin_amdgcn_perm(v.y, v.x, 0x0c040c00u)); eQ = sub(__builtin_amdgcn_perm(v.y, v.x, 0x0c050c01u));
+        oI = sub(__builtin_amdgcn_perm(v.y, v.x, 0x0c060c02u)); oQ = sub(__builtin_amdgcn_perm(v.y, v.x, 0x0c070c03u));
+    }
+};
+
 // five centre-tap dwords p[EB .. EB+4] of a lane whose p is 16-byte aligned (p = arm + 4t): as wide aligned
 // reads -- five separate ds_read_b32 with a lane stride of 16 bytes are 4-way bank conflicts each
 template<int EB>

@@ -19,27 +19,37 @@ __global__ void decim1_kernel(const uint32_t* __restrict__ in, uint32_t* __restr
     }
 }
 
-// new history = last DC_CHUNK samples of (old history ++ consumed input)
-__global__ void hist_update_kernel(const uint32_t* __restrict__ old_hist, const uint32_t* __restrict__ in,
-                                   uint32_t* __restrict__ new_hist, long n_in)
+// DecimatorsU::decimate1 (decimatorsu.h:218-230): (int16)((byte - Shift) << pre1); one complex sample = one uint16
+__global__ void decim1_u8_kernel(const uint16_t* __restrict__ in, uint32_t* __restrict__ out, long n, int pre, int shift)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= DC_CHUNK) return;
-    const long src = (long)i + n_in - DC_CHUNK;
-    new_hist[i] = src >= 0 ? in[src] : old_hist[i + n_in];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const uint32_t v = in[i];
+        const int re = (int)(v & 0xffu) - shift, im = (int)(v >> 8) - shift;
+        out[i] = pack_iq((int)((uint32_t)re << pre), (int)((uint32_t)im << pre));
+    }
 }
 
-typedef void (*chain_fn)(const uint4*, const uint4*, uint32_t*, const uint32_t*, long, int, int, int);
-typedef void (*fast_fn)(const uint4*, const uint4*, uint32_t*, uint32_t*, long, int, int, int);
+// new history = last `hist_dw` dwords of (old history ++ consumed input), all counted in dwords
+__global__ void hist_update_kernel(const uint32_t* __restrict__ old_hist, const uint32_t* __restrict__ in,
+                                   uint32_t* __restrict__ new_hist, long n_in_dw, int hist_dw)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hist_dw) return;
+    const long src = (long)i + n_in_dw - hist_dw;
+    new_hist[i] = src >= 0 ? in[src] : old_hist[i + n_in_dw];
+}
+
+typedef void (*chain_fn)(const void*, const void*, uint32_t*, const uint32_t*, long, int, int, int, int);
+typedef void (*fast_fn)(const void*, const void*, uint32_t*, uint32_t*, long, int, int, int, int);
 
 struct ChainEntry { chain_fn fn; fast_fn fast; const char* name; const char* fast_name; int lds; int fast_lds; };
 
-template<int L, int FC, int PRE> static ChainEntry entry()
+template<int L, int FC, int PRE, bool U8> static ChainEntry entry()
 {
     static char name[64], fname[64];
-    snprintf(name, sizeof name, "decim_chain_kernel<%d,%d,%d>", L, FC, PRE);
-    snprintf(fname, sizeof fname, "decim_fast_kernel<%d,%d,%d>", L, FC, PRE);
-    return ChainEntry{ &decim_chain_kernel<L, FC, PRE>, &decim_fast_kernel<L, FC, PRE>, name, fname,
+    snprintf(name, sizeof name, "decim_chain_kernel<%d,%d,%d,%d>", L, FC, PRE, (int)U8);
+    snprintf(fname, sizeof fname, "decim_fast_kernel<%d,%d,%d,%d>", L, FC, PRE, (int)U8);
+    return ChainEntry{ &decim_chain_kernel<L, FC, PRE, U8>, &decim_fast_kernel<L, FC, PRE, U8>, name, fname,
                        dc_lds_dwords(L) * 4, df_lds_dwords(L) * 4 };
 }
 
@@ -53,32 +63,33 @@ static void shifts(int bits, int log2, int* pre, int* post)
     else { *pre = 0; *post = log2; }
 }
 
-template<int L, int FC> static bool pick_pre(int pre, ChainEntry* e)
+template<int L, int FC> static bool pick_pre(int pre, bool u8, ChainEntry* e)
 {
-    // the only `pre` values decimation_shifts<16,{8,12,16}> produce for this L
+    // the only `pre` values decimation_shifts<16,{8,12,16}> produce for this L; DecimatorsU is <16,8> only
     constexpr int p12[7] = { 4, 3, 2, 1, 0, 0, 0 }, p8[7] = { 8, 7, 6, 5, 4, 3, 2 };
-    if (pre == 0)      { *e = entry<L, FC, 0>(); return true; }
-    if (pre == p12[L]) { *e = entry<L, FC, p12[L]>(); return true; }
-    if (pre == p8[L])  { *e = entry<L, FC, p8[L]>(); return true; }
+    if (u8) { if (pre != p8[L]) return false; *e = entry<L, FC, p8[L], true>(); return true; }
+    if (pre == 0)      { *e = entry<L, FC, 0, false>(); return true; }
+    if (pre == p12[L]) { *e = entry<L, FC, p12[L], false>(); return true; }
+    if (pre == p8[L])  { *e = entry<L, FC, p8[L], false>(); return true; }
     return false;
 }
-template<int L> static bool pick_fc(int fc, int pre, ChainEntry* e)
+template<int L> static bool pick_fc(int fc, int pre, bool u8, ChainEntry* e)
 {
     switch (fc) {
-    case 0: return pick_pre<L, 0>(pre, e);
-    case 1: return pick_pre<L, 1>(pre, e);
-    default: return pick_pre<L, 2>(pre, e);
+    case 0: return pick_pre<L, 0>(pre, u8, e);
+    case 1: return pick_pre<L, 1>(pre, u8, e);
+    default: return pick_pre<L, 2>(pre, u8, e);
     }
 }
-static bool pick(int L, int fc, int pre, ChainEntry* e)
+static bool pick(int L, int fc, int pre, bool u8, ChainEntry* e)
 {
     switch (L) {
-    case 1: return pick_fc<1>(fc, pre, e);
-    case 2: return pick_fc<2>(fc, pre, e);
-    case 3: return pick_fc<3>(fc, pre, e);
-    case 4: return pick_fc<4>(fc, pre, e);
-    case 5: return pick_fc<5>(fc, pre, e);
-    case 6: return pick_fc<6>(fc, pre, e);
+    case 1: return pick_fc<1>(fc, pre, u8, e);
+    case 2: return pick_fc<2>(fc, pre, u8, e);
+    case 3: return pick_fc<3>(fc, pre, u8, e);
+    case 4: return pick_fc<4>(fc, pre, u8, e);
+    case 5: return pick_fc<5>(fc, pre, u8, e);
+    case 6: return pick_fc<6>(fc, pre, u8, e);
     }
     return false;
 }
@@ -90,6 +101,9 @@ using namespace sdrx;
 struct sdrx_decim {
     int device = 0, log2 = 0, fcpos = 2, bits = 12, pre = 0, post = 0, group = 2;
     int cus = 256;
+    bool u8 = false;              // DecimatorsU flavour: quint8 I/Q input, value = byte - in_shift
+    int in_shift = 0;
+    int bps = 4;                  // bytes per complex input sample
     hipStream_t own_stream = nullptr, stream = nullptr;
     uint32_t* d_hist[2] = { nullptr, nullptr };
     int cur = 0;
@@ -124,15 +138,19 @@ static int choose_cps(long n_chunks, int slots)
     return (int)best;
 }
 
-static int launch(sdrx_decim* h, const int16_t* d_iq, long n_cplx, int16_t* d_out)
+static int launch(sdrx_decim* h, const void* d_iq, long n_cplx, int16_t* d_out)
 {
     // n_cplx: whole groups only (caller truncated)
     if (n_cplx <= 0) return SDRX_OK;
     if (h->log2 == 0) {
         const int block = 256;
         long grid = (n_cplx + block - 1) / block; if (grid > 4096) grid = 4096;
-        hipLaunchKernelGGL(decim1_kernel, dim3((unsigned)grid), dim3(block), 0, h->stream,
-                           reinterpret_cast<const uint32_t*>(d_iq), reinterpret_cast<uint32_t*>(d_out), n_cplx, h->pre);
+        if (h->u8)
+            hipLaunchKernelGGL(decim1_u8_kernel, dim3((unsigned)grid), dim3(block), 0, h->stream,
+                               static_cast<const uint16_t*>(d_iq), reinterpret_cast<uint32_t*>(d_out), n_cplx, h->pre, h->in_shift);
+        else
+            hipLaunchKernelGGL(decim1_kernel, dim3((unsigned)grid), dim3(block), 0, h->stream,
+                               static_cast<const uint32_t*>(d_iq), reinterpret_cast<uint32_t*>(d_out), n_cplx, h->pre);
         SDRX_HIP(hipGetLastError());
         snprintf(h->last_name, sizeof h->last_name, "decim1_kernel");
         h->last_grid = (int)grid; h->last_block = block; h->last_lds = 0;
@@ -140,8 +158,8 @@ static int launch(sdrx_decim* h, const int16_t* d_iq, long n_cplx, int16_t* d_ou
     }
     const long n_chunks = (n_cplx + DC_CHUNK - 1) / DC_CHUNK;
     if (n_chunks > 0x7fffffffL / 4) { set_error("input too long for one call"); return SDRX_EINVAL; }
-    const uint4* hist = reinterpret_cast<const uint4*>(h->d_hist[h->cur]);
-    const uint4* in4 = reinterpret_cast<const uint4*>(d_iq);
+    const void* hist = h->d_hist[h->cur];
+    const void* in4 = d_iq;
     uint32_t* out = reinterpret_cast<uint32_t*>(d_out);
     uint32_t* flags = nullptr;
     int trc = h->timer.begin(h->stream); if (trc) return trc;
@@ -163,7 +181,7 @@ static int launch(sdrx_decim* h, const int16_t* d_iq, long n_cplx, int16_t* d_ou
         }
         const long segs = (n_sub + spw - 1) / spw;
         hipLaunchKernelGGL(h->k.fast, dim3((unsigned)segs), dim3(64), 0, h->stream,
-                           hist, in4, out, flags, n_cplx, (int)n_sub, (int)spw, h->post);
+                           hist, in4, out, flags, n_cplx, (int)n_sub, (int)spw, h->post, h->in_shift);
         SDRX_HIP(hipGetLastError());
         snprintf(h->last_name, sizeof h->last_name, "%s", h->k.fast_name);
         h->last_grid = (int)segs; h->last_block = 64; h->last_lds = h->k.fast_lds;
@@ -173,7 +191,7 @@ static int launch(sdrx_decim* h, const int16_t* d_iq, long n_cplx, int16_t* d_ou
         long segs = (n_chunks + cps - 1) / cps;
         if (flags && segs > h->cus) segs = h->cus;       // fallback run: grid-stride scan of the flags
         hipLaunchKernelGGL(h->k.fn, dim3((unsigned)segs), dim3(DC_THREADS), 0, h->stream,
-                           hist, in4, out, static_cast<const uint32_t*>(flags), n_cplx, (int)n_chunks, cps, h->post);
+                           hist, in4, out, static_cast<const uint32_t*>(flags), n_cplx, (int)n_chunks, cps, h->post, h->in_shift);
         SDRX_HIP(hipGetLastError());
         if (h->path == 1) {
             snprintf(h->last_name, sizeof h->last_name, "%s", h->k.name);
@@ -181,8 +199,9 @@ static int launch(sdrx_decim* h, const int16_t* d_iq, long n_cplx, int16_t* d_ou
         }
     }
     trc = h->timer.end(h->stream); if (trc) return trc;
-    hipLaunchKernelGGL(hist_update_kernel, dim3(DC_CHUNK / 256), dim3(256), 0, h->stream,
-                       h->d_hist[h->cur], reinterpret_cast<const uint32_t*>(d_iq), h->d_hist[h->cur ^ 1], n_cplx);
+    const int hist_dw = DC_CHUNK * h->bps / 4;
+    hipLaunchKernelGGL(hist_update_kernel, dim3((unsigned)((hist_dw + 255) / 256)), dim3(256), 0, h->stream,
+                       h->d_hist[h->cur], static_cast<const uint32_t*>(d_iq), h->d_hist[h->cur ^ 1], n_cplx * h->bps / 4, hist_dw);
     SDRX_HIP(hipGetLastError());
     h->cur ^= 1;
     return SDRX_OK;
@@ -192,7 +211,20 @@ extern "C" {
 
 int sdrx_decim_group_int16(int log2_decim, int fcpos) { return group_int16(log2_decim, fcpos); }
 
+static int create_common(sdrx_decim_t** out, int device, int log2_decim, int fcpos, int input_bits, bool u8, int shift);
+
 int sdrx_decim_create(sdrx_decim_t** out, int device, int log2_decim, int fcpos, int input_bits)
+{
+    return create_common(out, device, log2_decim, fcpos, input_bits, false, 0);
+}
+
+int sdrx_decim_create_u8(sdrx_decim_t** out, int device, int log2_decim, int fcpos, int shift)
+{
+    if (shift < 0 || shift > 255) { set_error("sdrx_decim_create_u8: shift 0..255"); return SDRX_EINVAL; }
+    return create_common(out, device, log2_decim, fcpos, 8, true, shift);
+}
+
+static int create_common(sdrx_decim_t** out, int device, int log2_decim, int fcpos, int input_bits, bool u8, int shift)
 {
     if (!out) { set_error("sdrx_decim_create: null out"); return SDRX_EINVAL; }
     *out = nullptr;
@@ -207,18 +239,19 @@ int sdrx_decim_create(sdrx_decim_t** out, int device, int log2_decim, int fcpos,
     sdrx_decim* h = new (std::nothrow) sdrx_decim;
     if (!h) return SDRX_ENOMEM;
     h->device = device; h->log2 = log2_decim; h->fcpos = fcpos; h->bits = input_bits;
+    h->u8 = u8; h->in_shift = shift; h->bps = u8 ? 2 : 4;
     shifts(input_bits, log2_decim, &h->pre, &h->post);
     h->group = group_int16(log2_decim, fcpos);
     h->cus = device_cu_count(device);
     { const char* pe = getenv("SDRX_DECIM_PATH"); h->path = !pe ? 0 : !strcmp(pe, "exact") ? 1 : !strcmp(pe, "fast") ? 2 : 0; }
-    if (log2_decim > 0 && !pick(log2_decim, fcpos, h->pre, &h->k)) {
+    if (log2_decim > 0 && !pick(log2_decim, fcpos, h->pre, u8, &h->k)) {
         delete h; set_error("sdrx_decim_create: no kernel for this configuration"); return SDRX_EINVAL;
     }
     hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
     h->stream = h->own_stream;
     for (int i = 0; i < 2; i++) {
-        e = hipMalloc(reinterpret_cast<void**>(&h->d_hist[i]), DC_CHUNK * 4);
+        e = hipMalloc(reinterpret_cast<void**>(&h->d_hist[i]), (size_t)DC_CHUNK * h->bps);
         if (e != hipSuccess) { sdrx_decim_destroy(h); return hip_fail(e, "hipMalloc(hist)", __FILE__, __LINE__); }
     }
     *out = h;
@@ -241,7 +274,8 @@ int sdrx_decim_reset(sdrx_decim_t* h)
 {
     if (!h) return SDRX_EINVAL;
     SDRX_HIP(hipSetDevice(h->device));
-    SDRX_HIP(hipMemsetAsync(h->d_hist[h->cur], 0, DC_CHUNK * 4, h->stream));
+    // a zero SAMPLE: all-zero bytes for int16 input, the byte `in_shift` for the unsigned 8-bit flavour
+    SDRX_HIP(hipMemsetAsync(h->d_hist[h->cur], h->u8 ? h->in_shift : 0, (size_t)DC_CHUNK * h->bps, h->stream));
     return SDRX_OK;
 }
 
@@ -262,8 +296,43 @@ int sdrx_decim_sync(sdrx_decim_t* h)
     return SDRX_OK;
 }
 
+int sdrx_decim_process_u8(sdrx_decim_t* h, const uint8_t* iq, int32_t n_uint8, int16_t* out_iq, int32_t* n_out_cplx)
+{
+    if (!h || !h->u8) { set_error("sdrx_decim_process_u8: handle was not made by sdrx_decim_create_u8"); return SDRX_ESTATE; }
+    if (n_uint8 < 0 || (n_uint8 > 0 && (!iq || !out_iq))) { set_error("sdrx_decim_process_u8: bad argument"); return SDRX_EINVAL; }
+    SDRX_HIP(hipSetDevice(h->device));
+    const int64_t groups = n_uint8 / h->group;
+    const int64_t n_cplx = groups * (h->group / 2);
+    const int64_t n_out = n_cplx >> h->log2;
+    if (n_out_cplx) *n_out_cplx = (int32_t)n_out;
+    if (n_cplx == 0) return SDRX_OK;
+    int rc = h->d_in.reserve((size_t)n_cplx * 2); if (rc) return rc;
+    rc = h->d_out.reserve((size_t)n_out * 4); if (rc) return rc;
+    SDRX_HIP(hipMemcpyAsync(h->d_in.p, iq, (size_t)n_cplx * 2, hipMemcpyHostToDevice, h->stream));
+    rc = launch(h, h->d_in.p, (long)n_cplx, static_cast<int16_t*>(h->d_out.p));
+    if (rc) return rc;
+    SDRX_HIP(hipMemcpyAsync(out_iq, h->d_out.p, (size_t)n_out * 4, hipMemcpyDeviceToHost, h->stream));
+    SDRX_HIP(hipStreamSynchronize(h->stream));
+    return SDRX_OK;
+}
+
+int sdrx_decim_process_dev_u8(sdrx_decim_t* h, const uint8_t* d_iq, int64_t n_uint8, int16_t* d_out_iq, int64_t* n_out_cplx)
+{
+    if (!h || !h->u8) { set_error("sdrx_decim_process_dev_u8: handle was not made by sdrx_decim_create_u8"); return SDRX_ESTATE; }
+    if (n_uint8 < 0 || (n_uint8 > 0 && (!d_iq || !d_out_iq))) { set_error("sdrx_decim_process_dev_u8: bad argument"); return SDRX_EINVAL; }
+    if ((reinterpret_cast<uintptr_t>(d_iq) & 7u) || (reinterpret_cast<uintptr_t>(d_out_iq) & 3u)) {
+        set_error("sdrx_decim_process_dev_u8: d_iq must be 8-byte aligned"); return SDRX_EINVAL;
+    }
+    SDRX_HIP(hipSetDevice(h->device));
+    const int64_t groups = n_uint8 / h->group;
+    const int64_t n_cplx = groups * (h->group / 2);
+    if (n_out_cplx) *n_out_cplx = n_cplx >> h->log2;
+    return launch(h, d_iq, (long)n_cplx, d_out_iq);
+}
+
 int sdrx_decim_process_dev(sdrx_decim_t* h, const int16_t* d_iq, int64_t n_int16, int16_t* d_out_iq, int64_t* n_out_cplx)
 {
+    if (h && h->u8) { set_error("sdrx_decim_process_dev: handle takes unsigned 8-bit input, use the _u8 call"); return SDRX_ESTATE; }
     if (!h || n_int16 < 0 || (n_int16 > 0 && (!d_iq || !d_out_iq))) { set_error("sdrx_decim_process_dev: bad argument"); return SDRX_EINVAL; }
     if ((reinterpret_cast<uintptr_t>(d_iq) & 15u) || (reinterpret_cast<uintptr_t>(d_out_iq) & 3u)) {
         set_error("sdrx_decim_process_dev: d_iq must be 16-byte aligned"); return SDRX_EINVAL;
@@ -277,6 +346,7 @@ int sdrx_decim_process_dev(sdrx_decim_t* h, const int16_t* d_iq, int64_t n_int16
 
 int sdrx_decim_process(sdrx_decim_t* h, const int16_t* iq, int32_t n_int16, int16_t* out_iq, int32_t* n_out_cplx)
 {
+    if (h && h->u8) { set_error("sdrx_decim_process: handle takes unsigned 8-bit input, use the _u8 call"); return SDRX_ESTATE; }
     if (!h || n_int16 < 0 || (n_int16 > 0 && (!iq || !out_iq))) { set_error("sdrx_decim_process: bad argument"); return SDRX_EINVAL; }
     SDRX_HIP(hipSetDevice(h->device));
     const int64_t groups = n_int16 / h->group;
@@ -287,20 +357,20 @@ int sdrx_decim_process(sdrx_decim_t* h, const int16_t* iq, int32_t n_int16, int1
     int rc = h->d_in.reserve((size_t)n_cplx * 4); if (rc) return rc;
     rc = h->d_out.reserve((size_t)n_out * 4); if (rc) return rc;
     SDRX_HIP(hipMemcpyAsync(h->d_in.p, iq, (size_t)n_cplx * 4, hipMemcpyHostToDevice, h->stream));
-    rc = launch(h, static_cast<const int16_t*>(h->d_in.p), (long)n_cplx, static_cast<int16_t*>(h->d_out.p));
+    rc = launch(h, h->d_in.p, (long)n_cplx, static_cast<int16_t*>(h->d_out.p));
     if (rc) return rc;
     SDRX_HIP(hipMemcpyAsync(out_iq, h->d_out.p, (size_t)n_out * 4, hipMemcpyDeviceToHost, h->stream));
     SDRX_HIP(hipStreamSynchronize(h->stream));
     return SDRX_OK;
 }
 
-int64_t sdrx_decim_state_bytes(const sdrx_decim_t*) { return (int64_t)DC_CHUNK * 4; }
+int64_t sdrx_decim_state_bytes(const sdrx_decim_t* h) { return (int64_t)DC_CHUNK * (h ? h->bps : 4); }
 
 int sdrx_decim_get_state(sdrx_decim_t* h, void* host_buf)
 {
     if (!h || !host_buf) return SDRX_EINVAL;
     SDRX_HIP(hipSetDevice(h->device));
-    SDRX_HIP(hipMemcpyAsync(host_buf, h->d_hist[h->cur], DC_CHUNK * 4, hipMemcpyDeviceToHost, h->stream));
+    SDRX_HIP(hipMemcpyAsync(host_buf, h->d_hist[h->cur], (size_t)DC_CHUNK * h->bps, hipMemcpyDeviceToHost, h->stream));
     SDRX_HIP(hipStreamSynchronize(h->stream));
     return SDRX_OK;
 }
@@ -309,7 +379,7 @@ int sdrx_decim_set_state(sdrx_decim_t* h, const void* host_buf)
 {
     if (!h || !host_buf) return SDRX_EINVAL;
     SDRX_HIP(hipSetDevice(h->device));
-    SDRX_HIP(hipMemcpyAsync(h->d_hist[h->cur], host_buf, DC_CHUNK * 4, hipMemcpyHostToDevice, h->stream));
+    SDRX_HIP(hipMemcpyAsync(h->d_hist[h->cur], host_buf, (size_t)DC_CHUNK * h->bps, hipMemcpyHostToDevice, h->stream));
     SDRX_HIP(hipStreamSynchronize(h->stream));
     return SDRX_OK;
 }

@@ -82,6 +82,25 @@ def main():
                           "wrap": "see make_golden.py"}, "cuts_int16": cuts, "hashes": hashes},
               open(os.path.join(HERE, "decim_golden.json"), "w"), indent=0, sort_keys=True)
 
+    # ------------------------------------------------------------------ DecimatorsU<qint32, quint8, 16, 8, 127> (RTL-SDR)
+    ref.ref_decimu_new.restype = vp; ref.ref_decimu_free.argtypes = [vp]
+    ref.ref_decimu_process.restype = C.c_int; ref.ref_decimu_process.argtypes = [vp, C.c_int, C.c_int, vp, i32, vp]
+    xu = (synth.lcg_u32(2 * N, 15) & 0xff).astype(np.uint8)
+    xu[:2000] = 0; xu[2000:4000] = 255
+    uh = {}
+    for log2 in range(0, 7):
+        for fc in (0, 1, 2):
+            h = ref.ref_decimu_new(); outs = []
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                seg = np.ascontiguousarray(xu[a:b]); o = np.zeros(seg.size + 16, np.int16)
+                n = ref.ref_decimu_process(h, log2, fc, seg.ctypes.data, seg.size, o.ctypes.data)
+                outs.append(o[: 2 * n].copy())
+            ref.ref_decimu_free(h)
+            y = np.concatenate(outs)
+            uh[f"u8_log{log2}_fc{fc}"] = {"n": int(y.size // 2), "fnv1a64": f"{synth.fnv1a64(y):016x}"}
+    json.dump({"recipe": "(lcg_u32(2N,15) & 0xff), first 2000 bytes 0, next 2000 bytes 255; cuts as decim_golden", "hashes": uh},
+              open(os.path.join(HERE, "decimu_golden.json"), "w"), indent=0, sort_keys=True)
+
     # ------------------------------------------------------------------ DownChannelizer plans (real QObject class)
     q = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libsdrref_qt.so"))
     q.refqt_chan_new.restype = vp; q.refqt_chan_new.argtypes = [C.c_int] * 3

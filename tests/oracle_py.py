@@ -27,6 +27,8 @@ def _sig(L):
     L.sdro_decim_new.restype = vp; L.sdro_decim_new.argtypes = [C.c_int] * 3
     L.sdro_decim_free.argtypes = [vp]; L.sdro_decim_reset.argtypes = [vp]
     L.sdro_decim_process.restype = i32; L.sdro_decim_process.argtypes = [vp, vp, i32, vp]
+    L.sdro_decimu_new.restype = vp; L.sdro_decimu_new.argtypes = [C.c_int] * 3
+    L.sdro_decimu_process.restype = i32; L.sdro_decimu_process.argtypes = [vp, vp, i32, vp]
     L.sdro_decim_group_int16.restype = i32; L.sdro_decim_group_int16.argtypes = [C.c_int] * 2
     L.sdro_chan_plan.restype = i32; L.sdro_chan_plan.argtypes = [i32, i32, i32, vp, C.POINTER(i32), C.POINTER(i32)]
     L.sdro_chain_new.restype = vp; L.sdro_chain_new.argtypes = [i32, vp]
@@ -107,6 +109,23 @@ class Decim:
         buf = np.ascontiguousarray(buf, dtype=np.int16)
         out = np.empty(buf.size + 8, np.int16)
         n = self.L.sdro_decim_process(self.h, buf.ctypes.data, buf.size, out.ctypes.data)
+        return out[: 2 * n].copy()
+
+
+class DecimU:
+    def __init__(self, log2, fcpos, shift=127):
+        self.L = lib()
+        self.h = self.L.sdro_decimu_new(log2, fcpos, shift)
+        assert self.h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.sdro_decim_free(self.h); self.h = None
+
+    def process(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        out = np.empty(buf.size + 8, np.int16)
+        n = self.L.sdro_decimu_process(self.h, buf.ctypes.data, buf.size, out.ctypes.data)
         return out[: 2 * n].copy()
 
 

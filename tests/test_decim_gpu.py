@@ -88,3 +88,18 @@ def test_decim_device_path_large():
     want = orc.Decim(6, sa.FC_CEN, 12).process(x)
     assert n_out == want.size // 2 == (n // 64)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("fcpos", (sa.FC_CEN, sa.FC_INF, sa.FC_SUP))
+@pytest.mark.parametrize("log2", range(0, 7))
+def test_decimators_u8_rtlsdr_flavour(log2, fcpos):
+    """DecimatorsU<qint32, quint8, 16, 8, 127>: unsigned 8-bit I/Q, split calls, ragged tails"""
+    from tests import synth
+    n = 2 * 32768 + 4096 + 777
+    x = (synth.lcg_u32(2 * n, 900 + log2 * 3 + fcpos) & 0xff).astype(np.uint8)
+    x[: 2 * 3000] = 0; x[2 * 3000: 2 * 6000] = 255
+    g = sa.DecimatorsU(log2, fcpos, 127)
+    o = orc.DecimU(log2, fcpos, 127)
+    for a, b in ((0, 2 * 5000 + 2), (2 * 5000 + 2, 2 * 5000 + 2), (2 * 5000 + 2, 2 * 40001), (2 * 40001, 2 * n)):
+        got, want = g.decimate(x[a:b]), o.process(x[a:b])
+        assert got.size == want.size and np.array_equal(got, want), (log2, fcpos, a, b)

@@ -28,6 +28,18 @@ def test_decimators_vs_reference_hashes_on_gpu():
             assert np.array_equal(y, full[key]), key
 
 
+def test_decimators_u8_vs_reference_hashes_on_gpu():
+    from tests.test_oracle_golden import decimu_input
+    meta = json.load(open(os.path.join(G, "decim_golden.json")))
+    cuts, N = meta["cuts_int16"], meta["recipe"]["N"]
+    xu = decimu_input(N)
+    for key, want in json.load(open(os.path.join(G, "decimu_golden.json")))["hashes"].items():
+        _u, l, f = key.split("_")
+        d = sa.DecimatorsU(int(l[3:]), int(f[2:]), 127)
+        y = np.concatenate([d.decimate(xu[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+        assert y.size // 2 == want["n"] and f"{synth.fnv1a64(y):016x}" == want["fnv1a64"], key
+
+
 def test_channelizer_bank_vs_reference_feed_on_gpu():
     g = np.load(os.path.join(G, "chan_golden.npz"))
     cuts = [int(v) for v in g["cuts"]]

@@ -58,6 +58,23 @@ def test_decimators_all_variants_vs_reference_hashes():
     assert n_checked == 4 * 3 * 7 * 3
 
 
+def decimu_input(N):
+    xu = (synth.lcg_u32(2 * N, 15) & 0xff).astype(np.uint8)
+    xu[:2000] = 0; xu[2000:4000] = 255
+    return xu
+
+
+def test_decimators_u8_vs_reference_hashes():
+    meta = json.load(open(os.path.join(G, "decim_golden.json")))
+    cuts, N = meta["cuts_int16"], meta["recipe"]["N"]
+    xu = decimu_input(N)
+    for key, want in json.load(open(os.path.join(G, "decimu_golden.json")))["hashes"].items():
+        _u, l, f = key.split("_")
+        o = orc.DecimU(int(l[3:]), int(f[2:]), 127)
+        y = np.concatenate([o.process(xu[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+        assert y.size // 2 == want["n"] and f"{synth.fnv1a64(y):016x}" == want["fnv1a64"], key
+
+
 def test_group_strides_match_reference_loops():
     # `pos +=` of decimateK_* (decimators.h): the tail-drop granularity
     want = {(0, 2): 2, (1, 0): 8, (1, 2): 8, (2, 1): 16, (2, 2): 16, (3, 0): 32, (3, 2): 16,
