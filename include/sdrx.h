@@ -202,6 +202,25 @@ uint32_t sdrx_fifo_read_commit(sdrx_fifo_t* f, uint32_t count);
 /* samples dropped by overflowing writes since creation (the reference only logs them) */
 uint64_t sdrx_fifo_dropped(sdrx_fifo_t* f);
 
+/* ------------------------------------------------------------------------------------------
+ * .sdriq record files (sdrbase/dsp/filerecord.cpp:129-148; read by the FileSource plugin,
+ * plugins/samplesource/filesource/filesourceinput.cpp / filesourcethread.cpp:170-229).
+ * Layout: qint32 sampleRate | quint64 centerFrequency | time_t startTimeStamp | quint32 sampleSize, written
+ * field by field = 24 bytes, then raw `Sample`s.  readHeader() treats any sampleSize other than 16/24 as 16.
+ * Reference quirk kept visible: on end-of-file FileSourceThread::tick() rewinds to sizeof(FileRecord::Header),
+ * which is 32 with struct padding, i.e. loop playback skips the first two samples of the file.
+ * ------------------------------------------------------------------------------------------ */
+#define SDRX_SDRIQ_HEADER_BYTES 24
+#define SDRX_SDRIQ_LOOP_OFFSET  32
+typedef struct sdrx_sdriq_header {
+    int32_t  sample_rate;
+    uint64_t center_frequency;
+    int64_t  start_timestamp;
+    uint32_t sample_size;       /* 16 or 24 after parsing */
+} sdrx_sdriq_header;
+int sdrx_sdriq_parse_header(const uint8_t* bytes, uint64_t n_bytes, sdrx_sdriq_header* out);
+int sdrx_sdriq_write_header(uint8_t* bytes24, const sdrx_sdriq_header* hdr);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,6 +98,8 @@ def lib() -> C.CDLL:
         "sdrx_backend_read": (i64, [vp, i32, vp, i64]),
         "sdrx_backend_get_design": (C.c_int, [vp, i32, C.POINTER(i32), vp, i32, vp, C.POINTER(i32)]),
         "sdrx_backend_sync": (C.c_int, [vp]),
+        "sdrx_sdriq_parse_header": (C.c_int, [vp, C.c_uint64, vp]),
+        "sdrx_sdriq_write_header": (C.c_int, [vp, vp]),
         "sdrx_fifo_create": (C.c_int, [pp, u32]),
         "sdrx_fifo_destroy": (C.c_int, [vp]),
         "sdrx_fifo_set_size": (C.c_int, [vp, u32]),
@@ -310,6 +312,26 @@ class ChannelizerBank:
         g, b, l = C.c_int(), C.c_int(), C.c_int()
         _check(lib().sdrx_chan_bank_last_launch(self._h, name, 128, C.byref(g), C.byref(b), C.byref(l)), "last_launch")
         return {"kernel": name.value.decode(), "grid": g.value, "block": b.value, "lds_bytes": l.value}
+
+
+class SdriqHeader(C.Structure):
+    """sdrx_sdriq_header (FileRecord::Header, sdrbase/dsp/filerecord.h:17-23)"""
+    _fields_ = [("sample_rate", C.c_int32), ("center_frequency", C.c_uint64), ("start_timestamp", C.c_int64), ("sample_size", C.c_uint32)]
+
+
+def sdriq_parse(data: bytes):
+    """-> (SdriqHeader, int16 I/Q array of the samples that follow the 24-byte header)"""
+    h = SdriqHeader()
+    _check(lib().sdrx_sdriq_parse_header(data, len(data), C.byref(h)), "sdrx_sdriq_parse_header")
+    body = np.frombuffer(data, dtype=np.int16, offset=24, count=(len(data) - 24) // 4 * 2) if h.sample_size == 16 else None
+    return h, body
+
+
+def sdriq_header_bytes(sample_rate: int, center_frequency: int, timestamp: int = 0, sample_size: int = 16) -> bytes:
+    h = SdriqHeader(sample_rate, center_frequency, timestamp, sample_size)
+    buf = C.create_string_buffer(24)
+    _check(lib().sdrx_sdriq_write_header(buf, C.byref(h)), "sdrx_sdriq_write_header")
+    return buf.raw
 
 
 class BackendCfg(C.Structure):

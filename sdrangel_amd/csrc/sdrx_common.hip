@@ -115,6 +115,28 @@ int sdrx_device_count(void)
     return n;
 }
 
+/* ------------------------------------------------------------------ .sdriq header (filerecord.cpp:129-148) */
+int sdrx_sdriq_parse_header(const uint8_t* bytes, uint64_t n_bytes, sdrx_sdriq_header* out)
+{
+    if (!bytes || !out || n_bytes < SDRX_SDRIQ_HEADER_BYTES) { sdrx::set_error("sdrx_sdriq_parse_header: need 24 bytes"); return SDRX_EINVAL; }
+    std::memcpy(&out->sample_rate, bytes, 4);
+    std::memcpy(&out->center_frequency, bytes + 4, 8);
+    std::memcpy(&out->start_timestamp, bytes + 12, 8);
+    std::memcpy(&out->sample_size, bytes + 20, 4);
+    if (out->sample_size != 16 && out->sample_size != 24) out->sample_size = 16;   // "assume 16 bits if garbage (old I/Q file)"
+    return SDRX_OK;
+}
+
+int sdrx_sdriq_write_header(uint8_t* bytes24, const sdrx_sdriq_header* hdr)
+{
+    if (!bytes24 || !hdr) return SDRX_EINVAL;
+    std::memcpy(bytes24, &hdr->sample_rate, 4);
+    std::memcpy(bytes24 + 4, &hdr->center_frequency, 8);
+    std::memcpy(bytes24 + 12, &hdr->start_timestamp, 8);
+    std::memcpy(bytes24 + 20, &hdr->sample_size, 4);
+    return SDRX_OK;
+}
+
 /* ------------------------------------------------------------------ SampleSinkFifo mirror
  * Same observable contract as sdrbase/dsp/samplesinkfifo.cpp:70-231: a writer may add at most
  * size-fill samples (the rest is dropped and counted), readers see up to two contiguous spans,

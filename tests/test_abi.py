@@ -147,3 +147,27 @@ def test_fifo_data_ready_callback_fires_after_nonempty_write():
     f.write(_s([1]))
     f.write(_s([2, 3, 4, 5]))                           # partly dropped, still non-empty -> still signalled
     assert len(hits) == 2
+
+
+def test_sdriq_header_roundtrip_and_filesource_to_fifo():
+    """.sdriq layout of FileRecord::writeHeader (24 bytes, field by field) and the FileSource pump
+    (file bytes straight into SampleSinkFifo::write(const quint8*, uint), filesourcethread.cpp:213)."""
+    import struct
+    from tests import synth
+    x = synth.mix(3000, 8, 2047, 500)
+    blob = sa.sdriq_header_bytes(2_400_000, 433_920_000, 1_700_000_000, 16) + x.tobytes()
+    # the same 24 bytes struct.pack would give for qint32 | quint64 | time_t | quint32, little endian, unpadded
+    assert blob[:24] == struct.pack("<iQqI", 2_400_000, 433_920_000, 1_700_000_000, 16)
+    h, body = sa.sdriq_parse(blob)
+    assert (h.sample_rate, h.center_frequency, h.start_timestamp, h.sample_size) == (2_400_000, 433_920_000, 1_700_000_000, 16)
+    assert np.array_equal(body, x)
+    garbage = bytearray(blob); garbage[20:24] = struct.pack("<I", 12345)
+    assert sa.sdriq_parse(bytes(garbage))[0].sample_size == 16          # old files: "assume 16 bits if garbage"
+    with pytest.raises(sa.SdrxError):
+        sa.sdriq_parse(blob[:10])
+    # FileSourceThread::tick: chunks of file bytes -> fifo (rate * 4 samples large, filesourceinput.cpp:143)
+    fifo = sa.SampleSinkFifo(2_400_000 * 4)
+    data = blob[24:]
+    for off in range(0, len(data), 1000):
+        fifo.write_bytes(data[off: off + 1000])
+    assert fifo.fill == 3000 and np.array_equal(fifo.read(3000), x)
