@@ -159,8 +159,8 @@ typedef struct sdrx_backend_cfg {
     int32_t out_rate;        /* audio / demod rate; distance step = (Real) in_rate / (Real) out_rate; <= in_rate */
     float   interp_cutoff;   /* m_interpolator.create(16, in_rate, interp_cutoff, taps_per_phase) */
     float   taps_per_phase;  /* 4.5 (default, NFM) or 2.0 (SSB) */
-    int32_t filt_mode;       /* 0 none, 1 runFilt, 2 runSSB usb, 3 runSSB lsb  (getDC = true) */
-    float   f1, f2;          /* fftfilt(f1, f2, 1024): normalised to the OUTPUT rate */
+    int32_t filt_mode;       /* 0 none, 1 runFilt, 2 runSSB usb, 3 runSSB lsb, 4 runDSB  (getDC = true) */
+    float   f1, f2;          /* modes 1-3: fftfilt(f1, f2, 1024); mode 4: fftfilt(f2, 2048) (DSBFilter, ssbdemod.cpp:92); normalised to the OUTPUT rate */
     int32_t discri;          /* 0 none, 1 phaseDiscriminatorDelta (NFM), 2 phaseDiscriminator (UDPSrc) */
     float   fm_scaling;      /* setFMScaling */
 } sdrx_backend_cfg;
@@ -172,7 +172,8 @@ int sdrx_backend_feed_dev(sdrx_backend_t* h, const int16_t* const* d_iq, const i
 /* outputs of the last feed for channel ch: complex (re,im pairs) unless a discriminator is on;
  * returns the number of FLOATS written (<0: error) */
 int64_t sdrx_backend_read(sdrx_backend_t* h, int32_t ch, float* out, int64_t cap_floats);
-/* design products, for inspection: polyphase taps [16][ntaps], filter spectrum (1024 complex), NCO increment */
+/* design products, for inspection: polyphase taps [16][ntaps], filter spectrum (2048 complex slots; 1024 used
+ * unless filt_mode 4), NCO increment */
 int sdrx_backend_get_design(sdrx_backend_t* h, int32_t ch, int32_t* ntaps_per_phase, float* taps, int32_t taps_cap,
                             float* filter_iq, int32_t* nco_inc);
 int sdrx_backend_sync(sdrx_backend_t* h);

@@ -200,7 +200,7 @@ int64_t ref_backend_feed(void* h, const int16_t* iq, int64_t n_cplx, float* out_
 }
 
 // fftfilt overlap-add SSB/complex filter (fftfilt.cpp:261-325)
-void* ref_fftfilt_new(float f1, float f2, int len) { return new fftfilt(f1, f2, len); }
+void* ref_fftfilt_new(float f1, float f2, int len) { return f1 < 0 ? new fftfilt(f2, len) : new fftfilt(f1, f2, len); }
 void ref_fftfilt_free(void* h) { delete static_cast<fftfilt*>(h); }
 // mode 0: runFilt, 1: runSSB usb, 2: runSSB lsb, 3: runDSB
 int64_t ref_fftfilt_run(void* h, int mode, const float* in_iq, int64_t n, float* out_iq)

@@ -64,7 +64,8 @@ const float* sdro_backend_taps(const sdro_backend*);                     /* [pha
 void    sdro_gfft(float* iq, int32_t n, int32_t inverse);                /* gfft.h:3308-3330 */
 
 typedef struct sdro_fftfilt sdro_fftfilt;
-sdro_fftfilt* sdro_fftfilt_new(float f1, float f2, int32_t len);         /* fftfilt.cpp:77-84,108-146 */
+/* f1 >= 0: fftfilt(f1, f2, len) (fftfilt.cpp:77-84,108-146); f1 < 0: fftfilt(f2, len) = the DSB low pass (:86-93,149-170) */
+sdro_fftfilt* sdro_fftfilt_new(float f1, float f2, int32_t len);
 void    sdro_fftfilt_free(sdro_fftfilt*);
 const float* sdro_fftfilt_filter(const sdro_fftfilt*);                   /* len complex */
 /* mode 0 runFilt, 1 runSSB usb, 2 runSSB lsb, 3 runDSB (fftfilt.cpp:261-361) */

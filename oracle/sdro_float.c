@@ -7,10 +7,11 @@
  * addition is not associative and the parity bar is <= 1 ulp.
  *
  * g_fft restatement (sdrbase/dsp/gfft.h; forward ffts1 :1189-1224, inverse iffts1 :2238-2275), for
- * sizes N = 2^M with (M-1) % 3 == 0 (16, 128, 1024, 8192 -- fftfilt's 1024 included), i.e. the case
- * where the stage list is: bit-reversed load fused with one radix-2 stage (bitrevR2 :185-317 /
- * scbitrevR2 :1231-1363, the latter scaling by 1/N), then (M-1)/3 radix-8 passes (bfstages :843-1158 /
- * ibfstages :1889-2209).  The in-place index choreography of the reference has no effect on values;
+ * sizes N = 2^M with (M-1) % 3 in {0, 1}: 16, 128, 1024 (fftfilt SSB), 8192 and 32, 256, 2048 (fftfilt
+ * DSB), 16384.  Stage list: bit-reversed load fused with one radix-2 stage (bitrevR2 :185-317 /
+ * scbitrevR2 :1231-1363, the latter scaling by 1/N); when (M-1) % 3 == 1 one more radix-2 stage with the
+ * trivial twiddles 1 and -/+ i (bfR2 :531-635 / ibfR2 :1577-1681); then (M-1)/3 radix-8 passes (bfstages
+ * :843-1158 / ibfstages :1889-2209).  The in-place index choreography of the reference has no effect on values;
  * only the arithmetic forms below do.  With multiplier m = (mr, mi):
  *     PLUS (a,b,m): r = (a.r + b.r*mr) - b.i*mi ;  i = (a.i + b.r*mi) + b.i*mr     ( = a + b*m )
  *     MINUS(a,b,m): r = (a.r - b.r*mr) + b.i*mi ;  i = (a.i - b.r*mi) - b.i*mr     ( = a - b*m )
@@ -158,7 +159,7 @@ typedef struct { int M, N; float* u; } gfft;
 static int gfft_init(gfft* g, int n)
 {
     int M = 0; while ((1 << M) < n) M++;
-    if ((1 << M) != n || M < 4 || (M - 1) % 3 != 0) return -1;
+    if ((1 << M) != n || M < 4 || (M - 1) % 3 == 2) return -1;   /* (M-1)%3 == 2 would need the radix-4 stage bfR4 (not restated) */
     g->M = M; g->N = n;
     g->u = (float*)malloc(sizeof(float) * (size_t)(n / 4 + 1));
     /* fftCosInit (gfft.h:141-150): note the (float) casts of the index and of N */
@@ -188,9 +189,22 @@ static void gfft_run(const gfft* g, cf* x, int inverse)
         if (inverse) { s.r = scale * s.r; s.i = scale * s.i; d.r = scale * d.r; d.i = scale * d.i; }
         y[2 * j] = s; y[2 * j + 1] = d;
     }
-    /* radix-8 passes, D = 2, 16, 128, ... */
+    int D0 = 2;
+    if ((M - 1) % 3 == 1) {
+        /* bfR2 / ibfR2: pairs (k, k+2) with twiddle 1 and (k+1, k+3) with -i (forward) or +i (inverse), k = 0 mod 4 */
+        for (int k = 0; k < N; k += 4) {
+            const cf a = y[k], b = y[k + 2], c = y[k + 1], d = y[k + 3];
+            cf t;
+            t.r = a.r + b.r; t.i = a.i + b.i; y[k] = t;
+            t.r = a.r - b.r; t.i = a.i - b.i; y[k + 2] = t;
+            if (!inverse) { t.r = c.r + d.i; t.i = c.i - d.r; y[k + 1] = t; t.r = c.r - d.i; t.i = c.i + d.r; y[k + 3] = t; }
+            else          { t.r = c.r - d.i; t.i = c.i + d.r; y[k + 1] = t; t.r = c.r + d.i; t.i = c.i - d.r; y[k + 3] = t; }
+        }
+        D0 = 4;
+    }
+    /* radix-8 passes, D = D0, 8 D0, 64 D0, ... */
     const float sg = inverse ? 1.0f : -1.0f;                 /* forward multiplies by conj(w) */
-    for (int D = 2; D < N; D *= 8) {
+    for (int D = D0; D < N; D *= 8) {
         const int uinc = N / 8 / D;                          /* table step of w2 per twiddle index */
         for (int u = 0; u < D; u++) {
             /* w0 = e^{j 4t}, w1 = e^{j 2t}, w2 = e^{j t}, w3 = e^{j (t + pi/4)}, t = 2 pi u / (8 D), read from the
@@ -269,6 +283,10 @@ sdro_fftfilt* sdro_fftfilt_new(float f1, float f2, int32_t len)
     f->data = (cf*)calloc((size_t)len, sizeof(cf));
     f->ovl = (cf*)calloc((size_t)f->flen2, sizeof(cf));
     f->out = (cf*)calloc((size_t)f->flen2, sizeof(cf));
+    if (f1 < 0) {
+        /* fftfilt(float f2, int len) -> create_dsb_filter (fftfilt.cpp:86-93, 149-170): low pass only */
+        for (int i = 0; i < f->flen2; i++) { f->filter[i].r = fsinc(f2, i, f->flen2); f->filter[i].i = 0; }
+    } else {
     /* create_filter (fftfilt.cpp:108-146) */
     const int lp = f2 != 0, hp = f1 != 0;
     for (int i = 0; i < f->flen2; i++) {
@@ -277,6 +295,7 @@ sdro_fftfilt* sdro_fftfilt_new(float f1, float f2, int32_t len)
         if (hp) f->filter[i].r -= fsinc(f1, i, f->flen2);
     }
     if (hp && f2 < f1) f->filter[f->flen2 / 2].r += 1;
+    }
     for (int i = 0; i < f->flen2; i++) { const float w = blackman(i, f->flen2); f->filter[i].r *= w; f->filter[i].i *= w; }
     gfft_run(&f->g, f->filter, 0);
     float scale = 0;

@@ -382,7 +382,7 @@ class BackendBank:
     def design(self, ch: int):
         nt, inc = C.c_int32(), C.c_int32()
         taps = np.zeros(16 * 256, np.float32)
-        filt = np.zeros(2048, np.float32)
+        filt = np.zeros(4096, np.float32)
         _check(lib().sdrx_backend_get_design(self._h, ch, C.byref(nt), taps.ctypes.data, taps.size, filt.ctypes.data, C.byref(inc)),
                "sdrx_backend_get_design")
         return nt.value, taps[: 16 * nt.value].copy(), filt, inc.value

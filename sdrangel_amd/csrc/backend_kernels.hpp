@@ -21,7 +21,8 @@ namespace sdrx {
 
 constexpr int BE_HIST = 256;            // raw samples of history kept per channel (>= taps per phase)
 constexpr int BE_NCO_N = 4096;
-constexpr int BE_FFT = 1024;            // fftfilt length used by the demods (ssbdemod.h:36)
+constexpr int BE_FFT = 1024;            // SSB fftfilt length (ssbFftLen, ssbdemod.h:36); the DSB filter runs at 2 * BE_FFT
+constexpr int BE_FFT_MAX = 2048;
 
 struct BeChan {                         // device resident: config + carried state of one channel
     // --- config
@@ -30,8 +31,8 @@ struct BeChan {                         // device resident: config + carried sta
     int ntaps;                          // taps per phase
     int phase_steps;
     int taps_off;                       // float offset into the taps table: [phase][ntaps]
-    int filt_mode;                      // 0 none, 1 runFilt, 2 runSSB usb, 3 runSSB lsb
-    int filt_off;                       // complex offset into the filter table (BE_FFT entries)
+    int filt_mode;                      // 0 none, 1 runFilt, 2 runSSB usb, 3 runSSB lsb, 4 runDSB (fft length 2048)
+    int filt_off;                       // complex offset into the filter table (BE_FFT_MAX entries per channel)
     int discri;                         // 0 none, 1 phaseDiscriminatorDelta, 2 phaseDiscriminator
     float fm_scaling;
     // --- state
@@ -44,7 +45,7 @@ struct BeChan {                         // device resident: config + carried sta
     int n_res;                          // resampler outputs of this feed            (written by be_schedule)
     int n_blocks;                       // complete fftfilt blocks of this feed       (written by be_schedule)
     int n_out;                          // samples in the output buffer after this feed
-    int pad;
+    int half;                           // fftfilt block = flen / 2: 512, or 1024 for runDSB
 };
 
 struct BeBufs {                         // per channel device pointers (per feed capacity ensured by the host)
@@ -98,7 +99,7 @@ __global__ void be_schedule_kernel(BeChan* __restrict__ ch, const BeBufs* __rest
     }
     s.distance = d;
     s.n_res = cnt;
-    s.n_blocks = s.filt_mode ? (s.pending + cnt) / (BE_FFT / 2) : 0;
+    s.n_blocks = s.filt_mode ? (s.pending + cnt) / s.half : 0;
 }
 
 // ---- 2a. NCO mix of history + new samples into float (exact: int16 -> float, complex product)
@@ -161,26 +162,42 @@ __device__ __forceinline__ float2 c_minus(float2 a, float2 b, float mr, float mi
 __device__ __forceinline__ float2 c_two_minus(float2 a, float2 t)                 { float2 f; f.x = a.x * 2.0f - t.x; f.y = a.y * 2.0f - t.y; return f; }
 __device__ __forceinline__ float2 c_mul(float2 a, float2 b) { float2 t; t.x = a.x * b.x - a.y * b.y; t.y = a.x * b.y + a.y * b.x; return t; }
 
-// y: LDS work array (1024 float2); x: LDS input copy (1024 float2); u: cosine table (257 floats, global/LDS)
-// 128 threads.  inverse: first stage scaled by 1/1024, multipliers conjugated.
-template<bool INVERSE>
-__device__ __forceinline__ void gfft1024(float2* __restrict__ y, const float2* __restrict__ x, const float* __restrict__ u, int tid)
+// y: LDS work array (N float2); x: LDS input copy (N float2); u: cosine table (N/4+1 floats); N/8 threads.
+// N = 1024: stage list R2(bitrev) + 3 x radix-8 (D = 2, 16, 128);  N = 2048: R2(bitrev) + bfR2 (:531-635 /
+// ibfR2 :1577-1681: twiddles 1 and -/+i) + 3 x radix-8 (D = 4, 32, 256).  inverse: first stage scaled by 1/N,
+// multipliers conjugated.
+template<int N, bool INVERSE>
+__device__ __forceinline__ void gfft(float2* __restrict__ y, const float2* __restrict__ x, const float* __restrict__ u, int tid)
 {
-    constexpr int N = BE_FFT;
+    constexpr int NT = N / 8;
+    constexpr int M = N == 1024 ? 10 : 11;
+    static_assert(N == 1024 || N == 2048, "fftfilt lengths of the demods");
     const float scale = (float)(1.0 / N);
-    for (int j = tid; j < N / 2; j += 128) {
-        const unsigned r = __brev((unsigned)(2 * j)) >> 22;            // 10-bit reversal
+    for (int j = tid; j < N / 2; j += NT) {
+        const unsigned r = __brev((unsigned)(2 * j)) >> (32 - M);
         const float2 a = x[r], b = x[r + N / 2];
         float2 s, d; s.x = a.x + b.x; s.y = a.y + b.y; d.x = a.x - b.x; d.y = a.y - b.y;
         if (INVERSE) { s.x = scale * s.x; s.y = scale * s.y; d.x = scale * d.x; d.y = scale * d.y; }
         y[2 * j] = s; y[2 * j + 1] = d;
     }
     __syncthreads();
+    constexpr int D0 = N == 1024 ? 2 : 4;
+    if constexpr (N == 2048) {
+        for (int k = 4 * tid; k < N; k += 4 * NT) {
+            const float2 a = y[k], b = y[k + 2], c = y[k + 1], d = y[k + 3];
+            float2 t;
+            t.x = a.x + b.x; t.y = a.y + b.y; y[k] = t;
+            t.x = a.x - b.x; t.y = a.y - b.y; y[k + 2] = t;
+            if (!INVERSE) { t.x = c.x + d.y; t.y = c.y - d.x; y[k + 1] = t; t.x = c.x - d.y; t.y = c.y + d.x; y[k + 3] = t; }
+            else          { t.x = c.x - d.y; t.y = c.y + d.x; y[k + 1] = t; t.x = c.x + d.y; t.y = c.y - d.x; y[k + 3] = t; }
+        }
+        __syncthreads();
+    }
     const float sg = INVERSE ? 1.0f : -1.0f;
 #pragma unroll
-    for (int D = 2; D < N; D *= 8) {
+    for (int D = D0; D < N; D *= 8) {
         const int uinc = N / 8 / D;
-        const int uu = tid % D, g = tid / D;                           // 128 butterflies per pass
+        const int uu = tid % D, g = tid / D;                           // N/8 butterflies per pass
         const int i2 = uu * uinc, i1 = 2 * i2;
         int i0 = 4 * i2; float w0r;
         if (uu < D / 2) w0r = u[i0]; else { i0 = N / 2 - i0; w0r = -u[i0]; }
@@ -208,34 +225,36 @@ __device__ __forceinline__ void gfft1024(float2* __restrict__ y, const float2* _
     }
 }
 
-// ---- 3. fftfilt block: zero-padded forward FFT, filter, inverse FFT; writes head / tail halves
-__global__ __launch_bounds__(128)
+// ---- 3. fftfilt block: zero-padded forward FFT, filter, inverse FFT; writes head / tail halves.
+// One instantiation per FFT length; a workgroup whose channel uses the other length exits at once.
+template<int N>
+__global__ __launch_bounds__(N / 8)
 void be_fft_kernel(const BeChan* __restrict__ ch, const BeBufs* __restrict__ bufs,
                    const float2* __restrict__ filters, const float* __restrict__ utbl)
 {
-    __shared__ float2 xa[BE_FFT], ya[BE_FFT];
-    __shared__ float us[BE_FFT / 4 + 1];
+    constexpr int NT = N / 8, H = N / 2;
+    __shared__ float2 xa[N], ya[N];
+    __shared__ float us[N / 4 + 1];
     const int c = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
     const BeChan s = ch[c];
-    if (blk >= s.n_blocks) return;
+    if (s.half != H || blk >= s.n_blocks) return;
     const BeBufs b = bufs[c];
-    constexpr int H = BE_FFT / 2;
-    for (int i = tid; i <= BE_FFT / 4; i += 128) us[i] = utbl[i];
-    for (int i = tid; i < H; i += 128) { xa[i] = b.res[blk * H + i]; xa[H + i] = make_float2(0.0f, 0.0f); }
+    for (int i = tid; i <= N / 4; i += NT) us[i] = utbl[i];
+    for (int i = tid; i < H; i += NT) { xa[i] = b.res[blk * H + i]; xa[H + i] = make_float2(0.0f, 0.0f); }
     __syncthreads();
-    gfft1024<false>(ya, xa, us, tid);
+    gfft<N, false>(ya, xa, us, tid);
     const float2* filt = filters + s.filt_off;
-    for (int i = tid; i < H; i += 128) {
+    for (int i = tid; i < H; i += NT) {
         float2 lo = ya[i], hi = ya[H + i];
-        if (s.filt_mode == 1) { lo = c_mul(lo, filt[i]); hi = c_mul(hi, filt[H + i]); }          // runFilt
-        else if (i == 0) { lo = c_mul(lo, filt[0]); /* bin 512 is left untouched (fftfilt.cpp:294-311) */ }
+        if (s.filt_mode == 1 || s.filt_mode == 4) { lo = c_mul(lo, filt[i]); hi = c_mul(hi, filt[H + i]); }   // runFilt / runDSB (getDC)
+        else if (i == 0) { lo = c_mul(lo, filt[0]); /* bin N/2 is left untouched (fftfilt.cpp:294-311) */ }
         else if (s.filt_mode == 2) { lo = c_mul(lo, filt[i]); hi = make_float2(0.0f, 0.0f); }    // usb
         else { lo = make_float2(0.0f, 0.0f); hi = c_mul(hi, filt[H + i]); }                      // lsb
         xa[i] = lo; xa[H + i] = hi;
     }
     __syncthreads();
-    gfft1024<true>(ya, xa, us, tid);
-    for (int i = tid; i < H; i += 128) {
+    gfft<N, true>(ya, xa, us, tid);
+    for (int i = tid; i < H; i += NT) {
         b.head[blk * H + i] = ya[i];
         b.tail[(blk + 1) * H + i] = ya[H + i];
     }
@@ -265,7 +284,7 @@ __global__ void be_finish_kernel(BeChan* __restrict__ ch, const BeBufs* __restri
     const int c = blockIdx.y;
     const BeChan s = ch[c];
     const BeBufs b = bufs[c];
-    constexpr int H = BE_FFT / 2;
+    const int H = s.half;
     const int n = s.filt_mode ? s.n_blocks * H : s.n_res;
     auto sample = [&](int j) -> float2 {
         if (!s.filt_mode) return b.res[s.pending + j];
@@ -297,7 +316,7 @@ void be_carry_kernel(BeChan* __restrict__ ch, const BeBufs* __restrict__ bufs)
     const int c = blockIdx.x, tid = threadIdx.x;
     BeChan& s = ch[c];
     const BeBufs b = bufs[c];
-    constexpr int H = BE_FFT / 2;
+    const int H = s.half;
     const int n_in = s.n_in, n_res = s.n_res, pending = s.pending, nb = s.n_blocks;
     const int n = s.filt_mode ? nb * H : n_res;
     // discriminator memory = last sample of the finished stream
@@ -315,13 +334,13 @@ void be_carry_kernel(BeChan* __restrict__ ch, const BeBufs* __restrict__ bufs)
     }
     // fftfilt: unconsumed resampler outputs move to the front; ovlbuf = tail of the last block
     const int left = s.filt_mode ? (pending + n_res) - nb * H : 0;
-    float2 keep[2];
-    for (int q = 0; q < 2; q++) { const int i = q * 256 + tid; keep[q] = (s.filt_mode && i < left) ? b.res[nb * H + i] : make_float2(0.0f, 0.0f); }
-    float2 ov[2];
-    for (int q = 0; q < 2; q++) { const int i = q * 256 + tid; ov[q] = (s.filt_mode && nb > 0) ? b.tail[nb * H + i] : make_float2(0.0f, 0.0f); }
+    float2 keep[4];
+    for (int q = 0; q < 4; q++) { const int i = q * 256 + tid; keep[q] = (s.filt_mode && i < left) ? b.res[nb * H + i] : make_float2(0.0f, 0.0f); }
+    float2 ov[4];
+    for (int q = 0; q < 4; q++) { const int i = q * 256 + tid; ov[q] = (s.filt_mode && nb > 0 && i < H) ? b.tail[nb * H + i] : make_float2(0.0f, 0.0f); }
     __syncthreads();
-    for (int q = 0; q < 2; q++) { const int i = q * 256 + tid; if (s.filt_mode && i < left) b.res[i] = keep[q]; }
-    if (s.filt_mode && nb > 0) for (int q = 0; q < 2; q++) b.tail[q * 256 + tid] = ov[q];
+    for (int q = 0; q < 4; q++) { const int i = q * 256 + tid; if (s.filt_mode && i < left) b.res[i] = keep[q]; }
+    if (s.filt_mode && nb > 0) for (int q = 0; q < 4; q++) { const int i = q * 256 + tid; if (i < H) b.tail[i] = ov[q]; }
     if (tid == 0) {
         long p = ((long)s.nco_phase + (long)n_in * (long)s.nco_inc) % BE_NCO_N;
         if (p < 0) p += BE_NCO_N;
@@ -332,18 +351,20 @@ void be_carry_kernel(BeChan* __restrict__ ch, const BeBufs* __restrict__ bufs)
     }
 }
 
-// single forward FFT of one 1024-point block (filter design: fft->ComplexFFT(filter), fftfilt.cpp:131)
-__global__ __launch_bounds__(128)
+// single forward FFT of one block (filter design: fft->ComplexFFT(filter), fftfilt.cpp:131,158)
+template<int N>
+__global__ __launch_bounds__(N / 8)
 void be_fft_design_kernel(float2* __restrict__ data, const float* __restrict__ utbl)
 {
-    __shared__ float2 xa[BE_FFT], ya[BE_FFT];
-    __shared__ float us[BE_FFT / 4 + 1];
+    constexpr int NT = N / 8;
+    __shared__ float2 xa[N], ya[N];
+    __shared__ float us[N / 4 + 1];
     const int tid = threadIdx.x;
-    for (int i = tid; i <= BE_FFT / 4; i += 128) us[i] = utbl[i];
-    for (int i = tid; i < BE_FFT; i += 128) xa[i] = data[i];
+    for (int i = tid; i <= N / 4; i += NT) us[i] = utbl[i];
+    for (int i = tid; i < N; i += NT) xa[i] = data[i];
     __syncthreads();
-    gfft1024<false>(ya, xa, us, tid);
-    for (int i = tid; i < BE_FFT; i += 128) data[i] = ya[i];
+    gfft<N, false>(ya, xa, us, tid);
+    for (int i = tid; i < N; i += NT) data[i] = ya[i];
 }
 
 } // namespace sdrx

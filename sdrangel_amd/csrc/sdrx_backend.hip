@@ -82,7 +82,9 @@ struct sdrx_backend {
     int64_t sched_cap = 0;        // entries per channel
     BeBufs* h_bufs = nullptr;     // pinned: the per-feed table goes to the device in one async copy
     hipEvent_t bufs_ev = nullptr; // recorded behind that copy; waited on before the table is rewritten
-    float* d_nco = nullptr; float* d_taps = nullptr; float2* d_filters = nullptr; float* d_utbl = nullptr;
+    float* d_nco = nullptr; float* d_taps = nullptr; float2* d_filters = nullptr;
+    float* d_utbl = nullptr; float* d_utbl2 = nullptr;     // g_fft cosine tables for N = 1024 / 2048
+    bool any1024 = false, any2048 = false;
     std::vector<float> taps_all; std::vector<float> filters_all;     // kept for inspection (tests)
     std::vector<int> taps_off, filt_off, ntaps;
     bool state_valid = false;     // d_chan state initialised
@@ -96,7 +98,8 @@ static int ensure_capacity(sdrx_backend* b, int c, int64_t n_in)
     while (cap < n_in) cap *= 2;
     // pending (<512) + at most one resampler output per input (distance step >= 1 by construction of decimate())
     const size_t n_res_max = (size_t)cap + 1024;
-    const size_t n_blk_max = n_res_max / (BE_FFT / 2) + 2;
+    const size_t half = h.cfg.filt_mode == 4 ? BE_FFT : BE_FFT / 2;
+    const size_t n_blk_max = n_res_max / half + 2;
     // buffers that carry state (res: pending, tail: ovlbuf) must keep their content
     auto grow_keep = [&](DevBuf& buf, size_t bytes, size_t keep) -> int {
         if (bytes <= buf.cap) return SDRX_OK;
@@ -111,9 +114,9 @@ static int ensure_capacity(sdrx_backend* b, int c, int64_t n_in)
     };
     int rc;
     if ((rc = grow_keep(h.mixed, (size_t)(BE_HIST + cap) * 8, 0))) return rc;
-    if ((rc = grow_keep(h.res, n_res_max * 8, (BE_FFT / 2) * 8))) return rc;
-    if ((rc = grow_keep(h.head, n_blk_max * (BE_FFT / 2) * 8, 0))) return rc;
-    if ((rc = grow_keep(h.tail, (n_blk_max + 1) * (BE_FFT / 2) * 8, (BE_FFT / 2) * 8))) return rc;
+    if ((rc = grow_keep(h.res, (n_res_max + BE_FFT) * 8, BE_FFT * 8))) return rc;
+    if ((rc = grow_keep(h.head, n_blk_max * half * 8, 0))) return rc;
+    if ((rc = grow_keep(h.tail, (n_blk_max + 1) * half * 8, half * 8))) return rc;
     if ((rc = grow_keep(h.cplx_out, n_res_max * 8, 0))) return rc;
     if ((rc = grow_keep(h.real_out, n_res_max * 4, 0))) return rc;
     h.cap_in = cap;
@@ -141,6 +144,7 @@ int sdrx_backend_destroy(sdrx_backend_t* b)
     if (b->d_taps) (void)hipFree(b->d_taps);
     if (b->d_filters) (void)hipFree(b->d_filters);
     if (b->d_utbl) (void)hipFree(b->d_utbl);
+    if (b->d_utbl2) (void)hipFree(b->d_utbl2);
     if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
     delete b;
     return SDRX_OK;
@@ -153,7 +157,7 @@ int sdrx_backend_create(sdrx_backend_t** out, int device, int32_t n_ch, const sd
     if (n_ch <= 0 || !cfg) { set_error("sdrx_backend_create: bad argument"); return SDRX_EINVAL; }
     for (int c = 0; c < n_ch; c++) {
         const sdrx_backend_cfg& k = cfg[c];
-        if (k.in_rate <= 0 || k.out_rate <= 0 || k.out_rate > k.in_rate || k.filt_mode < 0 || k.filt_mode > 3 ||
+        if (k.in_rate <= 0 || k.out_rate <= 0 || k.out_rate > k.in_rate || k.filt_mode < 0 || k.filt_mode > 4 ||
             k.discri < 0 || k.discri > 2 || k.taps_per_phase <= 0 || k.taps_per_phase * 16 > BE_HIST) {
             set_error("sdrx_backend_create: bad channel configuration (need out_rate <= in_rate, taps_per_phase*16 <= 256)");
             return SDRX_EINVAL;
@@ -172,19 +176,23 @@ int sdrx_backend_create(sdrx_backend_t** out, int device, int32_t n_ch, const sd
 
 #define BE_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int r_ = hip_fail(e_, #call, __FILE__, __LINE__); sdrx_backend_destroy(b); return r_; } } while (0)
     // NCO table (nco.cpp:30-39) and g_fft cosine table (gfft.h:141-150)
-    std::vector<float> nco(BE_NCO_N), utbl(BE_FFT / 4 + 1);
+    std::vector<float> nco(BE_NCO_N);
     for (int i = 0; i < BE_NCO_N; i++) nco[(size_t)i] = (float)std::cos((2.0 * PI_D * i) / BE_NCO_N);
-    utbl[0] = 1.0f;
-    for (int i = 1; i < BE_FFT / 4; i++) utbl[(size_t)i] = (float)std::cos((2.0 * 3.141592653589793238462643383279502884197 * (float)i) / (float)BE_FFT);
-    utbl[BE_FFT / 4] = 0.0f;
     BE_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_nco), BE_NCO_N * 4));
-    BE_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_utbl), (BE_FFT / 4 + 1) * 4));
     BE_TRY(hipMemcpy(b->d_nco, nco.data(), BE_NCO_N * 4, hipMemcpyHostToDevice));
-    BE_TRY(hipMemcpy(b->d_utbl, utbl.data(), (BE_FFT / 4 + 1) * 4, hipMemcpyHostToDevice));
+    for (int n : { BE_FFT, BE_FFT_MAX }) {
+        std::vector<float> utbl((size_t)n / 4 + 1);
+        utbl[0] = 1.0f;
+        for (int i = 1; i < n / 4; i++) utbl[(size_t)i] = (float)std::cos((2.0 * 3.141592653589793238462643383279502884197 * (float)i) / (float)n);
+        utbl[(size_t)n / 4] = 0.0f;
+        float*& dst = n == BE_FFT ? b->d_utbl : b->d_utbl2;
+        BE_TRY(hipMalloc(reinterpret_cast<void**>(&dst), ((size_t)n / 4 + 1) * 4));
+        BE_TRY(hipMemcpy(dst, utbl.data(), ((size_t)n / 4 + 1) * 4, hipMemcpyHostToDevice));
+    }
 
     // per channel design
-    BE_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_filters), (size_t)n_ch * BE_FFT * 8));
-    b->filters_all.assign((size_t)n_ch * BE_FFT * 2, 0.0f);
+    BE_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_filters), (size_t)n_ch * BE_FFT_MAX * 8));
+    b->filters_all.assign((size_t)n_ch * BE_FFT_MAX * 2, 0.0f);
     for (int c = 0; c < n_ch; c++) {
         const sdrx_backend_cfg& k = cfg[c];
         ChanHost& h = b->ch[(size_t)c];
@@ -193,32 +201,39 @@ int sdrx_backend_create(sdrx_backend_t** out, int device, int32_t n_ch, const sd
         design_interp(16, (double)k.in_rate, (double)k.interp_cutoff, (double)k.taps_per_phase, poly, &nt);
         b->taps_off[(size_t)c] = (int)b->taps_all.size(); b->ntaps[(size_t)c] = nt;
         b->taps_all.insert(b->taps_all.end(), poly.begin(), poly.end());
-        b->filt_off[(size_t)c] = c * BE_FFT;
+        b->filt_off[(size_t)c] = c * BE_FFT_MAX;
+        const int flen = k.filt_mode == 4 ? BE_FFT_MAX : BE_FFT;
         if (k.filt_mode) {
-            // fftfilt::create_filter: windowed sinc in the first flen2 bins, forward FFT (on the GPU, with the
-            // same kernel code the data path uses), normalise to max |H| over bins 0..flen2-1
-            std::vector<float> f((size_t)BE_FFT * 2, 0.0f);
-            const int h2 = BE_FFT / 2;
-            const bool lp = k.f2 != 0, hp = k.f1 != 0;
-            for (int i = 0; i < h2; i++) {
-                float v = 0;
-                if (lp) v += fsinc(k.f2, i, h2);
-                if (hp) v -= fsinc(k.f1, i, h2);
-                f[(size_t)(2 * i)] = v;
+            // fftfilt::create_filter / create_dsb_filter: windowed sinc in the first flen2 bins, forward FFT (on the GPU,
+            // with the same kernel code the data path uses), normalise to max |H| over bins 0..flen2-1
+            std::vector<float> f((size_t)flen * 2, 0.0f);
+            const int h2 = flen / 2;
+            if (k.filt_mode == 4) {
+                for (int i = 0; i < h2; i++) f[(size_t)(2 * i)] = fsinc(k.f2, i, h2);            // fftfilt(f2, len): low pass only
+            } else {
+                const bool lp = k.f2 != 0, hp = k.f1 != 0;
+                for (int i = 0; i < h2; i++) {
+                    float v = 0;
+                    if (lp) v += fsinc(k.f2, i, h2);
+                    if (hp) v -= fsinc(k.f1, i, h2);
+                    f[(size_t)(2 * i)] = v;
+                }
+                if (hp && k.f2 < k.f1) f[(size_t)(2 * (h2 / 2))] += 1;
             }
-            if (hp && k.f2 < k.f1) f[(size_t)(2 * (h2 / 2))] += 1;
             for (int i = 0; i < h2; i++) { const float w = blackman(i, h2); f[(size_t)(2 * i)] *= w; f[(size_t)(2 * i + 1)] *= w; }
-            float2* dst = b->d_filters + (size_t)c * BE_FFT;
-            BE_TRY(hipMemcpy(dst, f.data(), BE_FFT * 8, hipMemcpyHostToDevice));
-            hipLaunchKernelGGL(be_fft_design_kernel, dim3(1), dim3(128), 0, b->stream, dst, b->d_utbl);
+            float2* dst = b->d_filters + (size_t)c * BE_FFT_MAX;
+            BE_TRY(hipMemcpy(dst, f.data(), (size_t)flen * 8, hipMemcpyHostToDevice));
+            if (flen == BE_FFT) hipLaunchKernelGGL(be_fft_design_kernel<BE_FFT>, dim3(1), dim3(BE_FFT / 8), 0, b->stream, dst, b->d_utbl);
+            else hipLaunchKernelGGL(be_fft_design_kernel<BE_FFT_MAX>, dim3(1), dim3(BE_FFT_MAX / 8), 0, b->stream, dst, b->d_utbl2);
             BE_TRY(hipGetLastError());
             BE_TRY(hipStreamSynchronize(b->stream));
-            BE_TRY(hipMemcpy(f.data(), dst, BE_FFT * 8, hipMemcpyDeviceToHost));
+            BE_TRY(hipMemcpy(f.data(), dst, (size_t)flen * 8, hipMemcpyDeviceToHost));
             float scale = 0;
             for (int i = 0; i < h2; i++) { const float mag = hypotf(f[(size_t)(2 * i)], f[(size_t)(2 * i + 1)]); if (mag > scale) scale = mag; }
-            if (scale != 0) for (int i = 0; i < BE_FFT * 2; i++) f[(size_t)i] /= scale;
-            BE_TRY(hipMemcpy(dst, f.data(), BE_FFT * 8, hipMemcpyHostToDevice));
-            std::memcpy(&b->filters_all[(size_t)c * BE_FFT * 2], f.data(), BE_FFT * 8);
+            if (scale != 0) for (int i = 0; i < flen * 2; i++) f[(size_t)i] /= scale;
+            BE_TRY(hipMemcpy(dst, f.data(), (size_t)flen * 8, hipMemcpyHostToDevice));
+            std::memcpy(&b->filters_all[(size_t)c * BE_FFT_MAX * 2], f.data(), (size_t)flen * 8);
+            (flen == BE_FFT ? b->any1024 : b->any2048) = true;
         }
         BeChan& s = b->h_chan[(size_t)c];
         std::memset(&s, 0, sizeof s);
@@ -227,6 +242,7 @@ int sdrx_backend_create(sdrx_backend_t** out, int device, int32_t n_ch, const sd
         s.ntaps = nt; s.phase_steps = 16;
         s.taps_off = b->taps_off[(size_t)c]; s.filt_mode = k.filt_mode; s.filt_off = b->filt_off[(size_t)c];
         s.discri = k.discri; s.fm_scaling = k.fm_scaling;
+        s.half = flen / 2;
         for (int i = 0; i < 2; i++) {
             BE_TRY(hipMalloc(reinterpret_cast<void**>(&h.hist[i]), BE_HIST * 4));
             BE_TRY(hipMemset(h.hist[i], 0, BE_HIST * 4));
@@ -281,9 +297,16 @@ static int feed_common(sdrx_backend* b, const int16_t* const* d_iq, const int64_
     SDRX_HIP(hipGetLastError());
     hipLaunchKernelGGL(be_fir_kernel, dim3(gx, (unsigned)b->n_ch), dim3(256), 0, b->stream, b->d_chan, b->d_bufs, b->d_taps);
     SDRX_HIP(hipGetLastError());
-    const unsigned max_blocks = (unsigned)((n_max + 1024) / (BE_FFT / 2) + 1);
-    hipLaunchKernelGGL(be_fft_kernel, dim3(max_blocks, (unsigned)b->n_ch), dim3(128), 0, b->stream, b->d_chan, b->d_bufs, b->d_filters, b->d_utbl);
-    SDRX_HIP(hipGetLastError());
+    if (b->any1024) {
+        const unsigned max_blocks = (unsigned)((n_max + BE_FFT) / (BE_FFT / 2) + 1);
+        hipLaunchKernelGGL(be_fft_kernel<BE_FFT>, dim3(max_blocks, (unsigned)b->n_ch), dim3(BE_FFT / 8), 0, b->stream, b->d_chan, b->d_bufs, b->d_filters, b->d_utbl);
+        SDRX_HIP(hipGetLastError());
+    }
+    if (b->any2048) {
+        const unsigned max_blocks = (unsigned)((n_max + BE_FFT_MAX) / (BE_FFT_MAX / 2) + 1);
+        hipLaunchKernelGGL(be_fft_kernel<BE_FFT_MAX>, dim3(max_blocks, (unsigned)b->n_ch), dim3(BE_FFT_MAX / 8), 0, b->stream, b->d_chan, b->d_bufs, b->d_filters, b->d_utbl2);
+        SDRX_HIP(hipGetLastError());
+    }
     hipLaunchKernelGGL(be_finish_kernel, dim3(gx, (unsigned)b->n_ch), dim3(256), 0, b->stream, b->d_chan, b->d_bufs);
     SDRX_HIP(hipGetLastError());
     hipLaunchKernelGGL(be_carry_kernel, dim3((unsigned)b->n_ch), dim3(256), 0, b->stream, b->d_chan, b->d_bufs);
@@ -339,7 +362,7 @@ int sdrx_backend_get_design(sdrx_backend_t* b, int32_t c, int32_t* ntaps_per_pha
     const int nt = b->ntaps[(size_t)c];
     if (ntaps_per_phase) *ntaps_per_phase = nt;
     if (taps) std::memcpy(taps, &b->taps_all[(size_t)b->taps_off[(size_t)c]], (size_t)std::min(taps_cap, nt * 16) * 4);
-    if (filter_iq) std::memcpy(filter_iq, &b->filters_all[(size_t)c * BE_FFT * 2], BE_FFT * 8);
+    if (filter_iq) std::memcpy(filter_iq, &b->filters_all[(size_t)c * BE_FFT_MAX * 2], BE_FFT_MAX * 8);
     if (nco_inc) *nco_inc = b->h_chan[(size_t)c].nco_inc;
     return SDRX_OK;
 }

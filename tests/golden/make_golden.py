@@ -178,6 +178,11 @@ def main():
         o = np.zeros(xr.size + 2048, np.float32)
         k = ref.ref_fftfilt_run(h, mode, xr.ctypes.data, xr.size // 2, o.ctypes.data)
         fl[f"fftfilt_{nm}"] = o[: 2 * k].copy()
+    h = ref.ref_fftfilt_new(-1.0, 2 * 3000 / 48000, 2048)              # DSBFilter (ssbdemod.cpp:92), runDSB
+    o = np.zeros(xr.size + 4096, np.float32)
+    k = ref.ref_fftfilt_run(h, 3, xr.ctypes.data, xr.size // 2, o.ctypes.data)
+    fl["fftfilt_dsb2048"] = o[: 2 * k].copy()
+    a = synth.noise_iq(2048, 33, 30000).astype(np.float32); ref.ref_gfft(a.ctypes.data, 2048, 0); fl["gfft2048_fwd"] = a
     y = fl["fftfilt_usb"]
     for kind, nm in ((0, "delta"), (1, "atan2")):
         o = np.zeros(y.size // 2, np.float32)

@@ -60,7 +60,8 @@ class Backend:
         L = lib(); _sig_float(L)
         self.L = L
         self.b = L.sdro_backend_new(float(nco_freq), float(in_rate), float(out_rate), 16, cutoff, tpp)
-        self.f = L.sdro_fftfilt_new(f1, f2, 1024) if filt_mode else None
+        self.flen = 2048 if filt_mode == 4 else 1024
+        self.f = (L.sdro_fftfilt_new(-1.0, f2, 2048) if filt_mode == 4 else L.sdro_fftfilt_new(f1, f2, 1024)) if filt_mode else None
         self.filt_mode, self.discri, self.fm = filt_mode, discri, fm_scaling
         self.last = None      # last sample seen by the discriminator (carried state)
         self.prev_tail = np.zeros(0, np.float32)
@@ -70,7 +71,7 @@ class Backend:
         return nt, np.ctypeslib.as_array(self.L.sdro_backend_taps(self.b), shape=(16 * nt,)).copy()
 
     def filter(self):
-        return np.ctypeslib.as_array(self.L.sdro_fftfilt_filter(self.f), shape=(2048,)).copy()
+        return np.ctypeslib.as_array(self.L.sdro_fftfilt_filter(self.f), shape=(2 * self.flen,)).copy()
 
     def feed(self, iq):
         iq = np.ascontiguousarray(iq, dtype=np.int16)
@@ -79,7 +80,7 @@ class Backend:
         k = self.L.sdro_backend_feed(self.b, iq.ctypes.data, n, res.ctypes.data)
         x = res[: 2 * k].copy()
         if self.filt_mode:
-            y = np.empty(x.size + 2048, np.float32)
+            y = np.empty(x.size + 4096, np.float32)
             m = self.L.sdro_fftfilt_run(self.f, self.filt_mode - 1, x.ctypes.data, k, y.ctypes.data)   # 1 runFilt, 2 usb, 3 lsb -> 0, 1, 2
             x = y[: 2 * m].copy()
         if not self.discri:

@@ -37,6 +37,12 @@ def test_float_oracle_vs_reference_vectors():
         k = L.sdro_fftfilt_run(h, mode, np.ascontiguousarray(xr).ctypes.data, xr.size // 2, o.ctypes.data)
         assert np.array_equal(bits(o[: 2 * k]), bits(g[f"fftfilt_{nm}"])), nm
         L.sdro_fftfilt_free(h)
+    h = L.sdro_fftfilt_new(-1.0, 2 * 3000 / 48000, 2048)
+    o = np.zeros(xr.size + 4096, np.float32)
+    k = L.sdro_fftfilt_run(h, 3, np.ascontiguousarray(xr).ctypes.data, xr.size // 2, o.ctypes.data)
+    assert np.array_equal(bits(o[: 2 * k]), bits(g["fftfilt_dsb2048"]))
+    a = synth.noise_iq(2048, 33, 30000).astype(np.float32); L.sdro_gfft(a.ctypes.data, 2048, 0)
+    assert np.array_equal(bits(a), bits(g["gfft2048_fwd"]))
     y = np.ascontiguousarray(g["fftfilt_usb"])
     o = np.zeros(y.size // 2, np.float32); L.sdro_discri(0, 24.0, y.ctypes.data, y.size // 2, o.ctypes.data)
     assert np.array_equal(bits(o), bits(g["discri_delta"]))

@@ -74,7 +74,7 @@ def test_float_backend_vs_reference():
     L.ref_discri.argtypes = [C.c_int, f32, vp, i64, vp]
     O = orc.lib(); orc._sig_float(O)
     rng = np.random.default_rng(9)
-    for n in (16, 128, 1024, 8192):
+    for n in (16, 32, 128, 256, 1024, 2048, 8192, 16384):
         for inv in (0, 1):
             x = (rng.standard_normal(2 * n) * 1000).astype(np.float32)
             a, b = x.copy(), x.copy()
@@ -95,6 +95,13 @@ def test_float_backend_vs_reference():
             A = np.zeros(2 * n + 8, np.float32); B = np.zeros(2 * n + 8, np.float32)
             ka = L.ref_fftfilt_run(hr, mode, x.ctypes.data, n, A.ctypes.data); kb = O.sdro_fftfilt_run(ho, mode, x.ctypes.data, n, B.ctypes.data)
             assert ka == kb and np.array_equal(A[: 2 * ka].view(np.uint32), B[: 2 * kb].view(np.uint32)), (f1, f2, mode)
+    # DSBFilter = new fftfilt(f2, 2 * ssbFftLen); runDSB  (ssbdemod.cpp:92,167)
+    n = 9000
+    x = (rng.standard_normal(2 * n) * 3000).astype(np.float32)
+    hr = L.ref_fftfilt_new(-1.0, 2 * 3000 / 48000, 2048); ho = O.sdro_fftfilt_new(-1.0, 2 * 3000 / 48000, 2048)
+    A = np.zeros(2 * n + 8, np.float32); B = np.zeros(2 * n + 8, np.float32)
+    ka = L.ref_fftfilt_run(hr, 3, x.ctypes.data, n, A.ctypes.data); kb = O.sdro_fftfilt_run(ho, 3, x.ctypes.data, n, B.ctypes.data)
+    assert ka == kb == 8192 and np.array_equal(A[: 2 * ka].view(np.uint32), B[: 2 * kb].view(np.uint32))
     x = (rng.standard_normal(20000) * 1000).astype(np.float32); x[:10] = 0
     for kind in (0, 1):
         A = np.zeros(10000, np.float32); B = np.zeros(10000, np.float32)
