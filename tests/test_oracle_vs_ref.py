@@ -107,3 +107,16 @@ def test_float_backend_vs_reference():
         A = np.zeros(10000, np.float32); B = np.zeros(10000, np.float32)
         L.ref_discri(kind, 24.0, x.ctypes.data, 10000, A.ctypes.data); O.sdro_discri(kind, 24.0, x.ctypes.data, 10000, B.ctypes.data)
         assert np.array_equal(A.view(np.uint32), B.view(np.uint32)), kind
+
+
+def test_qt_adapter_compiles_against_reference_headers():
+    """qt_adapter/GpuDownChannelizerBank (a real BasebandSampleSink subclass) builds with the reference's headers,
+    moc and libQt5Core of this image and links libsdrx.so -- source-level drop-in check (not run: needs a GPU + Qt loop)."""
+    import subprocess
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "qt_adapter_check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    if "adapter not checked" in r.stdout:
+        pytest.skip("moc / Qt5Core / libsdrx.so not available")
+    so = os.path.join(ROOT, "oracle", "_ref", "libsdrx_qt_adapter.so")
+    syms = subprocess.check_output(["nm", "-DC", "--defined-only", so], text=True)
+    assert "GpuDownChannelizerBank::feed" in syms and "GpuDownChannelizerBank::handleMessage" in syms
