@@ -23,7 +23,7 @@
 namespace sdrx {
 
 constexpr int TK_CHUNK = 4096;
-constexpr int TK_THREADS = 256;
+constexpr int TK_THREADS = 512;
 constexpr int TK_MAX_LEVELS = 6;
 constexpr int TK_HIST = 2 * TK_CHUNK;        // samples of stream history kept between feeds
 
@@ -74,7 +74,7 @@ __device__ __forceinline__ int div_pow2_trunc(int v, int n)
     return (v + ((v >> 31) & ((1 << n) - 1))) >> n;
 }
 
-__global__ __launch_bounds__(TK_THREADS, 2)
+__global__ __launch_bounds__(TK_THREADS, 4)
 void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restrict__ nodes,
                  const TkArray* __restrict__ arrays, const TkStream* __restrict__ streams,
                  const TkSink* __restrict__ sinks)
