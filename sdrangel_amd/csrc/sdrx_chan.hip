@@ -48,7 +48,7 @@ static int plan_chain(int32_t in_rate, int32_t req_rate, int32_t req_fc, uint8_t
 namespace {
 
 constexpr int MAX_STAGES = 30;
-constexpr int LDS_BUDGET_DW = 64 * 1024 / 4 - 64;          // two workgroups per CU
+constexpr int LDS_BUDGET_DW = 40 * 1024 / 4 - 64;          // four workgroups per CU
 constexpr int LDS_HARD_DW = 150 * 1024 / 4;
 
 struct HNode {
@@ -98,25 +98,30 @@ struct Group {
 
 int arm_len(int rel_depth) { return HIST / 2 + (TK_CHUNK >> (rel_depth + 2)); }   // dwords
 
-// LDS dwords a subtree of `levels` levels below trie node `root` needs
+// LDS dwords a subtree of `levels` levels below trie node `root` needs: two arm regions (even / odd producer
+// level, each as large as its biggest level), 16 dwords of persistent history per array, the node table
+// (a lower/upper sibling pair shares one entry)
 int subtree_lds(const std::vector<HNode>& trie, int root, int levels, int* n_nodes_out)
 {
-    int lds = 0, n_nodes = 0;
+    int region[2] = { 0, 0 }, n_arrays = 0, n_entries = 0;
     std::vector<int> cur{ root };
     for (int rel = 0; rel < levels; rel++) {
         std::vector<int> nxt;
+        int level_dw = 0;
         for (int id : cur) {
             bool c = trie[id].child[0] >= 0, lu = trie[id].child[1] >= 0 || trie[id].child[2] >= 0;
             if (!c && !lu) continue;
-            lds += arm_len(rel) * (2 + (c ? 2 : 0) + (lu ? 2 : 0));
+            const int na = 2 + (c ? 2 : 0) + (lu ? 2 : 0);
+            level_dw += arm_len(rel) * na; n_arrays += na;
+            n_entries += (c ? 1 : 0) + (lu ? 1 : 0);
             for (int m = 0; m < 3; m++) if (trie[id].child[m] >= 0) nxt.push_back(trie[id].child[m]);
         }
-        n_nodes += (int)nxt.size();
+        region[rel & 1] = std::max(region[rel & 1], level_dw);
         cur.swap(nxt);
         if (cur.empty()) break;
     }
-    *n_nodes_out = n_nodes;
-    return lds + n_nodes * 16;
+    *n_nodes_out = n_entries;
+    return region[0] + region[1] + n_arrays * 16 + n_entries * TK_NODE_DW;
 }
 
 int height(const std::vector<HNode>& trie, int id)
@@ -191,14 +196,22 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
         st.n_levels = levels;
         st.node_base = (int)g->nodes.size();
         st.array_base = (int)g->arrays.size();
-        int off = 0;
+        // window offsets are assigned per producer level inside region (level & 1); fixed up to absolute LDS offsets below
+        int reg_used[2] = { 0, 0 }, reg_size[2] = { 0, 0 }, cur_level = 0;
         struct Arms { int E[2], O[2], A[2]; };
         auto alloc_arms = [&](int id, int rel, bool inner) {
             Arms a; a.E[0] = a.E[1] = a.O[0] = a.O[1] = a.A[0] = a.A[1] = -1;
             const bool c = g->trie[id].child[0] >= 0, lu = g->trie[id].child[1] >= 0 || g->trie[id].child[2] >= 0;
             if (!inner || (!c && !lu)) return a;
             const int len = arm_len(rel);
-            auto take = [&]() { int o = off; off += len; g->arrays.push_back(TkArray{ o, len }); return o; };
+            if (rel != cur_level) { cur_level = rel; reg_used[rel & 1] = 0; }
+            // returns the INDEX of the array (relative to the subtree's list); node fields are patched to offsets later
+            auto take = [&]() {
+                const int idx = (int)g->arrays.size() - st.array_base;
+                g->arrays.push_back(TkArray{ reg_used[rel & 1], len, rel & 1, 0 });   // store: region id for now
+                reg_used[rel & 1] += len; reg_size[rel & 1] = std::max(reg_size[rel & 1], reg_used[rel & 1]);
+                return idx;
+            };
             a.E[0] = take(); a.E[1] = take();
             if (c) { a.O[0] = take(); a.O[1] = take(); }
             if (lu) { a.A[0] = take(); a.A[1] = take(); }
@@ -206,9 +219,8 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
         };
         std::vector<int> cur{ root };
         std::vector<Arms> cur_arms{ alloc_arms(root, 0, true) };
-        st.rootE_I = cur_arms[0].E[0]; st.rootE_Q = cur_arms[0].E[1];
-        st.rootO_I = cur_arms[0].O[0]; st.rootO_Q = cur_arms[0].O[1];
-        st.rootA_I = cur_arms[0].A[0]; st.rootA_Q = cur_arms[0].A[1];
+        const Arms root_arms = cur_arms[0];
+        st.root_arr_cnt = (int)g->arrays.size() - st.array_base;
         int rel_nodes = 0;
         for (int rel = 1; rel <= levels; rel++) {
             std::vector<int> nxt; std::vector<Arms> nxt_arms;
@@ -217,54 +229,94 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
             lv.nout = TK_CHUNK >> rel;
             int jl = 0; while ((8 << jl) < lv.nout) jl++;
             lv.jobs_log2 = jl;
+            lv.arr_base = (int)g->arrays.size() - st.array_base;
+            int n_entries = 0;
             for (size_t pi = 0; pi < cur.size(); pi++) {
+                const Arms pa = cur_arms[pi];
+                int kid[3]; Arms own[3];
                 for (int m = 0; m < 3; m++) {
-                    const int id = g->trie[cur[pi]].child[m];
-                    if (id < 0) continue;
-                    const Arms& pa = cur_arms[pi];
-                    const Arms own = alloc_arms(id, rel, rel < levels);
-                    TkNode nd; memset(&nd, 0xff, sizeof nd);
-                    if (m == SDRX_MODE_CENTER) {
-                        nd.oddI = pa.O[0]; nd.oddQ = pa.O[1]; nd.cenI = pa.E[0]; nd.cenQ = pa.E[1];
-                        nd.cIe = pk16(0, 2048); nd.cIo = pk16(2048, 0); nd.cQe = pk16(0, 2048); nd.cQo = pk16(2048, 0);
-                    } else {
-                        nd.oddI = pa.A[0]; nd.oddQ = pa.A[1]; nd.cenI = pa.E[1]; nd.cenQ = pa.E[0];   // I <- eQ, Q <- eI
+                    kid[m] = g->trie[cur[pi]].child[m];
+                    if (kid[m] < 0) continue;
+                    own[m] = alloc_arms(kid[m], rel, rel < levels);
+                    nxt.push_back(kid[m]); nxt_arms.push_back(own[m]);
+                }
+                // one stage's output side: arms, centre taps, sinks (channel ends; a node stream if the tree goes on below this pass)
+                auto fill = [&](TkOut& o, int m) {
+                    const int id = kid[m];
+                    o.present = 1;
+                    o.outE_I = own[m].E[0]; o.outE_Q = own[m].E[1];
+                    o.outO_I = own[m].O[0]; o.outO_Q = own[m].O[1];
+                    o.outA_I = own[m].A[0]; o.outA_Q = own[m].A[1];
+                    if (m == SDRX_MODE_CENTER) { o.cIe = pk16(0, 2048); o.cIo = pk16(2048, 0); o.cQe = pk16(0, 2048); o.cQo = pk16(2048, 0); }
+                    else {
                         const int sg = m == SDRX_MODE_LOWER ? 1 : -1;
                         // lower: k odd -> (-im, re), k even -> (im, -re); upper: the negation
-                        nd.cIo = pk16(-2048 * sg, 0); nd.cQo = pk16(2048 * sg, 0);
-                        nd.cIe = pk16(0, 2048 * sg);  nd.cQe = pk16(0, -2048 * sg);
+                        o.cIo = pk16(-2048 * sg, 0); o.cQo = pk16(2048 * sg, 0);
+                        o.cIe = pk16(0, 2048 * sg);  o.cQe = pk16(0, -2048 * sg);
                     }
-                    nd.outE_I = own.E[0]; nd.outE_Q = own.E[1];
-                    nd.outO_I = own.O[0]; nd.outO_Q = own.O[1];
-                    nd.outA_I = own.A[0]; nd.outA_Q = own.A[1];
-                    nd.sink = -1; nd.pad = 0;
-                    // sinks: channel ends, and a node stream if the tree continues below this pass
+                    o.sink = -1;
                     for (int c : g->trie[id].ends) {
-                        SinkInfo sk{ 0, c, -1, g->trie[id].depth, nd.sink };
-                        g->sinks.push_back(sk); nd.sink = (int)g->sinks.size() - 1;
-                        b->ch[c].sink = nd.sink;
+                        SinkInfo sk{ 0, c, -1, g->trie[id].depth, o.sink };
+                        g->sinks.push_back(sk); o.sink = (int)g->sinks.size() - 1;
+                        b->ch[c].sink = o.sink;
                     }
                     const bool has_kids = g->trie[id].child[0] >= 0 || g->trie[id].child[1] >= 0 || g->trie[id].child[2] >= 0;
                     if (rel == levels && has_kids) {
                         Stream ms; ms.trie_node = id; ms.depth = g->trie[id].depth; ms.pass = pass + 1;
-                        SinkInfo sk{ 1, -1, (int)g->streams.size(), g->trie[id].depth, nd.sink };
-                        g->sinks.push_back(sk); nd.sink = (int)g->sinks.size() - 1;
-                        ms.sink = nd.sink;
+                        SinkInfo sk{ 1, -1, (int)g->streams.size(), g->trie[id].depth, o.sink };
+                        g->sinks.push_back(sk); o.sink = (int)g->sinks.size() - 1;
+                        ms.sink = o.sink;
                         g->trie[id].stream = (int)g->streams.size();
                         g->streams.push_back(std::move(ms));
                     }
-                    g->nodes.push_back(nd);
-                    nxt.push_back(id); nxt_arms.push_back(own);
-                    rel_nodes++;
+                };
+                if (kid[SDRX_MODE_CENTER] >= 0) {
+                    TkNode nd; memset(&nd, 0xff, sizeof nd);
+                    nd.oddI = pa.O[0]; nd.oddQ = pa.O[1]; nd.cenI = pa.E[0]; nd.cenQ = pa.E[1];
+                    fill(nd.a, SDRX_MODE_CENTER);
+                    nd.b.present = 0;
+                    g->nodes.push_back(nd); n_entries++;
+                }
+                if (kid[SDRX_MODE_LOWER] >= 0 || kid[SDRX_MODE_UPPER] >= 0) {
+                    // lower and upper siblings read the same alternating-sign odd arm and differ only in the centre tap:
+                    // fused into one entry (a = first present, b = the other)
+                    TkNode nd; memset(&nd, 0xff, sizeof nd);
+                    nd.oddI = pa.A[0]; nd.oddQ = pa.A[1]; nd.cenI = pa.E[1]; nd.cenQ = pa.E[0];   // I <- eQ, Q <- eI
+                    nd.b.present = 0;
+                    if (kid[SDRX_MODE_LOWER] >= 0) {
+                        fill(nd.a, SDRX_MODE_LOWER);
+                        if (kid[SDRX_MODE_UPPER] >= 0) fill(nd.b, SDRX_MODE_UPPER);
+                    } else fill(nd.a, SDRX_MODE_UPPER);
+                    g->nodes.push_back(nd); n_entries++;
                 }
             }
-            lv.n_nodes = (int)nxt.size();
+            rel_nodes += n_entries;
+            lv.arr_cnt = (int)g->arrays.size() - st.array_base - lv.arr_base;
+            lv.n_nodes = n_entries;
             cur.swap(nxt); cur_arms.swap(nxt_arms);
         }
         st.n_nodes = rel_nodes;
         st.n_arrays = (int)g->arrays.size() - st.array_base;
-        st.node_tab = off;
-        st.lds_dwords = off + rel_nodes * 16;
+        // absolute layout: [region 0][region 1][history store: 16 dwords per array][node table]
+        const int reg_base[2] = { 0, reg_size[0] };
+        const int store_base = reg_size[0] + reg_size[1];
+        for (int i = 0; i < st.n_arrays; i++) {
+            TkArray& a = g->arrays[(size_t)(st.array_base + i)];
+            a.off += reg_base[a.store]; a.store = store_base + 16 * i;
+        }
+        auto fix = [&](int& v) { if (v >= 0) v = g->arrays[(size_t)(st.array_base + v)].off; };
+        { Arms r = root_arms; for (int q = 0; q < 2; q++) { fix(r.E[q]); fix(r.O[q]); fix(r.A[q]); }
+          st.rootE_I = r.E[0]; st.rootE_Q = r.E[1]; st.rootO_I = r.O[0]; st.rootO_Q = r.O[1]; st.rootA_I = r.A[0]; st.rootA_Q = r.A[1]; }
+        for (int i = 0; i < rel_nodes; i++) {
+            TkNode& nd = g->nodes[(size_t)(st.node_base + i)];
+            fix(nd.oddI); fix(nd.oddQ); fix(nd.cenI); fix(nd.cenQ);
+            for (TkOut* o : { &nd.a, &nd.b }) {
+                if (!o->present) continue;
+                fix(o->outE_I); fix(o->outE_Q); fix(o->outO_I); fix(o->outO_Q); fix(o->outA_I); fix(o->outA_Q);
+            }
+        }
+        st.node_tab = store_base + 16 * st.n_arrays;
+        st.lds_dwords = st.node_tab + rel_nodes * TK_NODE_DW;
         g->max_lds_dw = std::max(g->max_lds_dw, st.lds_dwords);
         g->streams[si].subtree = (int)g->subtrees.size();
         g->subtrees.push_back(st);

@@ -23,34 +23,56 @@
 namespace sdrx {
 
 constexpr int TK_CHUNK = 4096;
-constexpr int TK_THREADS = 512;
+constexpr int TK_THREADS = 256;
 constexpr int TK_MAX_LEVELS = 6;
 constexpr int TK_HIST = 2 * TK_CHUNK;        // samples of stream history kept between feeds
 
-struct TkNode {                 // 64 B, one half-band stage
-    int oddI, oddQ;             // LDS dword offsets: odd arm it reads (parent's plain or alt copy)
-    int cenI, cenQ;             // even-arm arrays feeding the I / Q accumulators (swapped for L/U)
-    uint32_t cIe, cIo, cQe, cQo;// packed centre taps for even / odd output index
+// One table entry = one half-band stage, or a FUSED lower/upper sibling pair: the lower- and the upper-half
+// child of a node rotate the odd arm identically (j^(n+1) = (-j)^(n+1) for odd n) and only differ in the sign
+// of the centre tap, so 24 of their 25 taps are one shared sum.  The pair costs 12.5 + 2 dot2 per output and
+// component instead of 2 x 13.5, and reads the parent's window once.
+struct TkOut {                  // 12 dwords: where one stage's outputs go + its centre taps
     int outE_I, outE_Q;         // own output arms (-1: none): even
     int outO_I, outO_Q;         //   odd, plain (for a centre child)
     int outA_I, outA_Q;         //   odd, alternating wrap-negated (for lower/upper children)
-    int sink, pad;              // head of this node's sink list (index into the sink table), -1: none
+    int sink;                   // head of this stage's sink list (index into the sink table), -1: none
+    int present;                // 0: this half of the entry is unused
+    uint32_t cIe, cIo, cQe, cQo;// packed centre taps for even / odd output index
 };
+constexpr int TK_NODE_DW = 32;
+struct TkNode {                 // 32 dwords
+    int oddI, oddQ;             // LDS dword offsets: odd arm it reads (parent's plain or alt copy)
+    int cenI, cenQ;             // even-arm arrays feeding the I / Q accumulators (swapped for L/U)
+    TkOut a;                    // the stage itself (the LOWER child when fused)
+    TkOut b;                    // the UPPER sibling when fused (present = 1)
+    int pad[4];
+};
+static_assert(sizeof(TkOut) == 48 && sizeof(TkNode) == TK_NODE_DW * 4, "node table layout");
 
-struct TkLevel { int node_base, n_nodes, jobs_log2, nout; };   // nout = outputs per node per chunk
+struct TkLevel {
+    int node_base, n_nodes, jobs_log2, nout;     // nout = outputs per node per chunk
+    int arr_base, arr_cnt;                       // arrays PRODUCED by this level's stages (relative to the subtree's array list)
+    int pad[2];
+};
 
 struct TkSubtree {
     int n_levels;
     int n_nodes;                // all levels
     int node_base;              // first node (global index) -- levels index relative to the table
-    int n_arrays, array_base;   // carry list
-    int lds_dwords;             // arms + node table copy
+    int n_arrays, array_base;   // all arrays: [root arrays][level-1 arrays][level-2 arrays]...
+    int root_arr_cnt;           // the first root_arr_cnt arrays are the root arms
+    int lds_dwords;             // two arm regions + history store + node table copy
     int node_tab;               // LDS dword offset of the node table copy
     int rootE_I, rootE_Q, rootO_I, rootO_Q, rootA_I, rootA_Q;   // root arms (-1: none)
     TkLevel lv[TK_MAX_LEVELS];
 };
 
-struct TkArray { int off, len; };            // LDS dword offset / length of one polyphase array
+// One polyphase array.  Its window [off, off+len) = 16 dwords of history + the chunk's payload lives in one of
+// two LDS regions that alternate by tree level (level l's arrays are dead once level l+1 has consumed them, so
+// level l+2 reuses the space: 61 KB -> 40 KB for the cfg-3 raw pass, 2 -> 4 workgroups per CU); the 16-dword
+// history survives in a persistent slot `store`: saved when the consumer level is done, restored in front of
+// the window before the producer writes the next chunk.
+struct TkArray { int off, len, store, pad; };
 
 struct TkStream {               // per feed, per input stream of a pass
     const uint32_t* hist;       // TK_HIST samples: absolute positions [t_old - TK_HIST, t_old)
@@ -74,7 +96,7 @@ __device__ __forceinline__ int div_pow2_trunc(int v, int n)
     return (v + ((v >> 31) & ((1 << n) - 1))) >> n;
 }
 
-__global__ __launch_bounds__(TK_THREADS, 4)
+__global__ __launch_bounds__(TK_THREADS, 2)
 void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restrict__ nodes,
                  const TkArray* __restrict__ arrays, const TkStream* __restrict__ streams,
                  const TkSink* __restrict__ sinks)
@@ -91,9 +113,9 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
 
     for (int i = tid; i < st.lds_dwords; i += NT) lds[i] = 0;
     __syncthreads();
-    {   // node table -> LDS (16 dwords per node)
+    {   // node table -> LDS
         const uint32_t* src = reinterpret_cast<const uint32_t*>(nodes + st.node_base);
-        for (int i = tid; i < st.n_nodes * 16; i += NT) lds[st.node_tab + i] = src[i];
+        for (int i = tid; i < st.n_nodes * TK_NODE_DW; i += NT) lds[st.node_tab + i] = src[i];
     }
 
     uint4 pre[LPT];
@@ -134,6 +156,10 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                 lds[st.rootA_Q + q] = ((0u - oQ) & 0xffffu) | (oQ & 0xffff0000u);
             }
         }
+        for (int i = tid; i < st.root_arr_cnt * 16; i += NT) {                 // history in front of the root windows
+            const TkArray a = arrays[st.array_base + (i >> 4)];
+            lds[a.off + (i & 15)] = lds[a.store + (i & 15)];
+        }
         if (chunk < last) fetch(chunk + 1);
         __syncthreads();
 
@@ -141,13 +167,18 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
         for (int l = 0; l < st.n_levels; l++) {
             const TkLevel lv = st.lv[l];
             const int njobs = lv.n_nodes << lv.jobs_log2;
+            for (int i = tid; i < lv.arr_cnt * 16; i += NT) {                      // history of the arrays this level produces
+                const TkArray a = arrays[st.array_base + lv.arr_base + (i >> 4)];
+                lds[a.off + (i & 15)] = lds[a.store + (i & 15)];
+            }
             for (int j = tid; j < njobs; j += NT) {
                 const int ni = lv.node_base + (j >> lv.jobs_log2);
                 const int t = j & ((1 << lv.jobs_log2) - 1);
-                const uint4* nt = reinterpret_cast<const uint4*>(lds + st.node_tab + ni * 16);
-                const uint4 n0 = nt[0], n1 = nt[1], n2 = nt[2], n3 = nt[3];
-                // --- the stage: 8 outputs, packed int16 arms, centre taps from the node
-                int yI[8], yQ[8];
+                const uint4* nt = reinterpret_cast<const uint4*>(lds + st.node_tab + ni * TK_NODE_DW);
+                const uint4 n0 = nt[0];
+                // --- shared part: 8 outputs x (I,Q) of the 24-tap odd-arm sum, packed int16 arms
+                int sI[8], sQ[8];
+                uint32_t vI[5], vQ[5];
                 {
                     const uint32_t* oI = lds + (int)n0.x, *oQ = lds + (int)n0.y;
                     const uint32_t* cI = lds + (int)n0.z, *cQ = lds + (int)n0.w;
@@ -161,7 +192,6 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                         wQ[4*q] = b.x; wQ[4*q+1] = b.y; wQ[4*q+2] = b.z; wQ[4*q+3] = b.w;
                     }
                     constexpr int EB = (32 - (hb_pairs<48>() - 1) - 1) / 2;      // 10
-                    uint32_t vI[5], vQ[5];
                     ld_centre5<EB>(cI + 4 * t, vI);
                     ld_centre5<EB>(cQ + 4 * t, vQ);
                     static_for<0, 8>([&](auto rc) {
@@ -172,59 +202,72 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                             constexpr uint32_t cf = pk_coef<48, MODE_CEN>(r, d);
                             if constexpr (cf != 0) { aI = dot2(wI[d], cf, aI); aQ = dot2(wQ[d], cf, aQ); }
                         });
+                        sI[r] = aI; sQ[r] = aQ;
+                    });
+                }
+                const long abs0 = chunk * lv.nout + 8 * t;
+                // --- per stage of the entry: centre tap, int16 store, own arms, sinks
+                auto emit = [&](const uint4 o0, const uint4 o1, const uint4 oc) {
+                    int yI[8], yQ[8];
+                    static_for<0, 8>([&](auto rc) {
+                        constexpr int r = decltype(rc)::value;
                         constexpr int dd = (r + 1) >> 1;
-                        aI = dot2(vI[dd], (r & 1) ? n1.y : n1.x, aI);
-                        aQ = dot2(vQ[dd], (r & 1) ? n1.w : n1.z, aQ);
+                        const int aI = dot2(vI[dd], (r & 1) ? oc.y : oc.x, sI[r]);
+                        const int aQ = dot2(vQ[dd], (r & 1) ? oc.w : oc.z, sQ[r]);
                         yI[r] = (int)(int16_t)(aI >> (HB_SHIFT - 1));               // Sample::setReal (:828)
                         yQ[r] = (int)(int16_t)(aQ >> (HB_SHIFT - 1));
                     });
-                }
-                // --- own arms for the children
-                if ((int)n2.x >= 0) {
-                    const int p = HIST / 2 + 2 * t;
-                    const uint32_t e0I = pack_iq(yI[0], yI[2]), e1I = pack_iq(yI[4], yI[6]);
-                    const uint32_t e0Q = pack_iq(yQ[0], yQ[2]), e1Q = pack_iq(yQ[4], yQ[6]);
-                    *reinterpret_cast<uint2*>(lds + (int)n2.x + p) = make_uint2(e0I, e1I);
-                    *reinterpret_cast<uint2*>(lds + (int)n2.y + p) = make_uint2(e0Q, e1Q);
-                    const uint32_t o0I = pack_iq(yI[1], yI[3]), o1I = pack_iq(yI[5], yI[7]);
-                    const uint32_t o0Q = pack_iq(yQ[1], yQ[3]), o1Q = pack_iq(yQ[5], yQ[7]);
-                    if ((int)n2.z >= 0) {
-                        *reinterpret_cast<uint2*>(lds + (int)n2.z + p) = make_uint2(o0I, o1I);
-                        *reinterpret_cast<uint2*>(lds + (int)n2.w + p) = make_uint2(o0Q, o1Q);
-                    }
-                    if ((int)n3.x >= 0) {
-                        auto alt = [](uint32_t v) { return ((0u - v) & 0xffffu) | (v & 0xffff0000u); };
-                        *reinterpret_cast<uint2*>(lds + (int)n3.x + p) = make_uint2(alt(o0I), alt(o1I));
-                        *reinterpret_cast<uint2*>(lds + (int)n3.y + p) = make_uint2(alt(o0Q), alt(o1Q));
-                    }
-                }
-                // --- global sinks (channel ends and node streams for the next pass)
-                if (live) {
-                    const long abs0 = chunk * lv.nout + 8 * t;
-                    for (int si = (int)n3.z; si >= 0; ) {
-                        const TkSink sk = sinks[si];
-#pragma unroll
-                        for (int r = 0; r < 8; r++) {
-                            const long a = abs0 + r;
-                            if (a >= sk.lo && a < sk.hi) {
-                                const int re = sk.shift ? div_pow2_trunc(yI[r], sk.shift) : yI[r];
-                                const int im = sk.shift ? div_pow2_trunc(yQ[r], sk.shift) : yQ[r];
-                                sk.ptr[a - sk.base] = pack_iq(re, im);
-                            }
+                    if ((int)o0.x >= 0) {                                          // own arms for the children
+                        const int p = HIST / 2 + 2 * t;
+                        const uint32_t e0I = pack_iq(yI[0], yI[2]), e1I = pack_iq(yI[4], yI[6]);
+                        const uint32_t e0Q = pack_iq(yQ[0], yQ[2]), e1Q = pack_iq(yQ[4], yQ[6]);
+                        *reinterpret_cast<uint2*>(lds + (int)o0.x + p) = make_uint2(e0I, e1I);
+                        *reinterpret_cast<uint2*>(lds + (int)o0.y + p) = make_uint2(e0Q, e1Q);
+                        const uint32_t o0I = pack_iq(yI[1], yI[3]), o1I = pack_iq(yI[5], yI[7]);
+                        const uint32_t o0Q = pack_iq(yQ[1], yQ[3]), o1Q = pack_iq(yQ[5], yQ[7]);
+                        if ((int)o0.z >= 0) {
+                            *reinterpret_cast<uint2*>(lds + (int)o0.z + p) = make_uint2(o0I, o1I);
+                            *reinterpret_cast<uint2*>(lds + (int)o0.w + p) = make_uint2(o0Q, o1Q);
                         }
-                        si = sk.next;
+                        if ((int)o1.x >= 0) {
+                            auto alt = [](uint32_t v) { return ((0u - v) & 0xffffu) | (v & 0xffff0000u); };
+                            *reinterpret_cast<uint2*>(lds + (int)o1.x + p) = make_uint2(alt(o0I), alt(o1I));
+                            *reinterpret_cast<uint2*>(lds + (int)o1.y + p) = make_uint2(alt(o0Q), alt(o1Q));
+                        }
                     }
+                    if (live) {                                                    // channel ends / node streams
+                        for (int si = (int)o1.z; si >= 0; ) {
+                            const TkSink sk = sinks[si];
+                            const long rel = abs0 - sk.lo, span = sk.hi - sk.lo;
+                            uint32_t* dst = sk.ptr + (abs0 - sk.base);
+                            if (rel >= 0 && rel + 8 <= span) {                     // whole job in range: no per-sample guards
+#pragma unroll
+                                for (int r = 0; r < 8; r++)
+                                    dst[r] = sk.shift ? pack_iq(div_pow2_trunc(yI[r], sk.shift), div_pow2_trunc(yQ[r], sk.shift))
+                                                      : pack_iq(yI[r], yQ[r]);
+                            } else if (rel > -8 && rel < span) {
+#pragma unroll
+                                for (int r = 0; r < 8; r++)
+                                    if (rel + r >= 0 && rel + r < span)
+                                        dst[r] = sk.shift ? pack_iq(div_pow2_trunc(yI[r], sk.shift), div_pow2_trunc(yQ[r], sk.shift))
+                                                          : pack_iq(yI[r], yQ[r]);
+                            }
+                            si = sk.next;
+                        }
+                    }
+                };
+                emit(nt[1], nt[2], nt[3]);
+                if ((int)nt[5].w != 0) emit(nt[4], nt[5], nt[6]);                  // fused upper sibling
+            }
+            {   // the arrays this level READ are complete and still intact: keep their last 16 dwords for the next chunk
+                const int sb = l == 0 ? 0 : st.lv[l - 1].arr_base, sc = l == 0 ? st.root_arr_cnt : st.lv[l - 1].arr_cnt;
+                for (int i = tid; i < sc * 16; i += NT) {
+                    const TkArray a = arrays[st.array_base + sb + (i >> 4)];
+                    lds[a.store + (i & 15)] = lds[a.off + a.len - 16 + (i & 15)];
                 }
             }
             __syncthreads();
         }
-
-        // ---- carry: last 32 int16 (16 dwords) of every array become the next chunk's history
-        for (int i = tid; i < st.n_arrays * 16; i += NT) {
-            const TkArray a = arrays[st.array_base + (i >> 4)];
-            lds[a.off + (i & 15)] = lds[a.off + a.len - 16 + (i & 15)];
-        }
-        __syncthreads();
     }
 }
 
