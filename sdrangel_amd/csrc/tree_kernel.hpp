@@ -96,7 +96,7 @@ __device__ __forceinline__ int div_pow2_trunc(int v, int n)
     return (v + ((v >> 31) & ((1 << n) - 1))) >> n;
 }
 
-__global__ __launch_bounds__(TK_THREADS, 2)
+__global__ __launch_bounds__(TK_THREADS, 4)
 void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restrict__ nodes,
                  const TkArray* __restrict__ arrays, const TkStream* __restrict__ streams,
                  const TkSink* __restrict__ sinks)
