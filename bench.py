@@ -86,6 +86,48 @@ def cpu_baseline(sample_cplx: int, reps: int, log2: int = 6):
                       f"one independent stream per thread ({n_thr} threads); single_thread_MSps = 1 thread, as sdrangelbench runs it"}
 
 
+def cpu_baseline_chan(fcs, sample_cplx: int):
+    """Reference DownChannelizer stage chains (IntHalfbandFilterEO<qint32,qint32,48> objects driven by the loop of
+    DownChannelizer::feed), every channel re-filtering the full-rate stream on its own thread like
+    ThreadedBasebandSampleSink does (threadedbasebandsamplesink.cpp:74-78); value = input MS/s the host sustains
+    for the WHOLE bank."""
+    import numpy as np
+    from tests import oracle_py as orc
+    n_thr = max(1, min(os.cpu_count() or 1, 16, len(fcs)))
+    x = orc.synth_iq(sample_cplx, seed=77, amp=2047)
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libsdrref.so")
+    plans = [orc.chan_plan(61_440_000, 48000, int(fc))[0] for fc in fcs]
+    kind = "port"
+    L = None
+    if os.path.exists(ref_so):
+        try:
+            L = C.CDLL(ref_so)
+            L.ref_chain_new.restype = C.c_void_p; L.ref_chain_new.argtypes = [C.c_int, C.c_void_p]
+            L.ref_chain_feed.restype = C.c_int64; L.ref_chain_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+            kind = "reference"
+        except OSError:
+            L = None
+    if L is not None:
+        hs = [L.ref_chain_new(len(m), np.ascontiguousarray(m).ctypes.data) for m in plans]
+        feed = lambda h, out: L.ref_chain_feed(h, x.ctypes.data, sample_cplx, out.ctypes.data)
+    else:
+        O = orc.lib(fast=os.path.exists(os.path.join(ROOT, "oracle", "libsdro_fast.so")))
+        hs = [O.sdro_chain_new(len(m), np.ascontiguousarray(m).ctypes.data) for m in plans]
+        feed = lambda h, out: O.sdro_chain_feed(h, x.ctypes.data, sample_cplx, out.ctypes.data)
+    outs = [np.empty(sample_cplx // 64 + 64, np.int16) for _ in hs]
+    def work(t):
+        for c in range(t, len(hs), n_thr):
+            feed(hs[c], outs[c])
+    th = [threading.Thread(target=work, args=(t,)) for t in range(n_thr)]
+    t0 = time.perf_counter()
+    for t in th: t.start()
+    for t in th: t.join()
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_cplx / dt / 1e6, 3), "unit": "MS/s", "cores": n_thr, "kind": kind,
+            "sample": f"{len(fcs)} DownChannelizer chains (one per channel, each over the full-rate stream) on {sample_cplx} synthetic samples, "
+                      f"{n_thr} host threads, channels dealt round-robin; value = input rate sustained for the whole bank"}
+
+
 def load_traffic(kernel: str, batch: int, workload: str):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/*traffic*.json), or None."""
     import glob
@@ -109,6 +151,7 @@ def main():
     ap.add_argument("--workload", default="decim64", choices=["decim64", "chan32", "chan128", "cfg4"])
     ap.add_argument("--batch", type=int, default=256 * 1024 * 1024, help="complex samples per step per GPU (1 GiB of int16 I/Q)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary cfg-3 (32-channel bank) measurement")
     args = ap.parse_args()
 
     import sdrangel_amd as sa
@@ -201,8 +244,39 @@ def main():
                          "algorithmic_bytes_per_sample": bytes_per_sample,
                          "grid": ll["grid"], "block": ll["block"], "lds_bytes": ll["lds_bytes"]},
         }
+        if n_gpus == 1 and args.workload == "decim64" and not args.no_also:
+            # the other half of the metric's name: BASELINE configs[2], 32-channel DownChannelizer bank, same GPU, same run
+            nb = 64 * 1024 * 1024
+            k32 = torch.arange(32, dtype=torch.float64)
+            fcs32 = (-15_000_000 + k32 * (30_000_000 / 31) + 137 * k32).to(torch.int64).tolist()
+            bank = sa.ChannelizerBank(61_440_000, [48000] * 32, fcs32, device=dev.index)
+            bank.set_stream(stream)
+            def bstep():
+                bank.feed_dev(x.data_ptr(), nb)
+                for c in range(32):
+                    bank.skip(c)
+            for _ in range(2):
+                bstep()
+            torch.cuda.synchronize(dev)
+            bank.set_timing(True)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                bstep()
+            torch.cuda.synchronize(dev)
+            bel = time.perf_counter() - t0
+            bms, bn = bank.get_timing()
+            bms /= max(bn, 1)
+            bps = 4.0 + 32 * 4.0 / 1024
+            line["also"] = {"chan32": {"workload": "cfg3: DownChannelizer bank, 32 channels x 48 kS/s from one 61.44 MS/s-shaped stream, %d samples per feed" % nb,
+                                       "value": round(5 * nb / bel / 1e6, 1), "unit": "MS/s", "kernel": "tree_kernel (all passes of a feed)",
+                                       "kernel_ms": round(bms, 4), "algorithmic_bytes_per_sample": bps,
+                                       "roofline_frac": round(bps * nb / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+            del bank
         if n_gpus == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(8 * 1024 * 1024, 16)
+            if args.workload == "decim64":
+                line["cpu_baseline"] = cpu_baseline(8 * 1024 * 1024, 16)
+            else:
+                line["cpu_baseline"] = cpu_baseline_chan(fcs, 4 * 1024 * 1024)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
