@@ -11,8 +11,8 @@
 //     stage 6     : int32 arms, lane = (output pair, component, quarter of the taps) + DPP adds
 //
 // Exactness: stage 1 is exact for ANY int16 input.  Stages 2 and 3 read their inputs as int16;
-// that is exact iff every stage-1 and stage-2 output fits int16, which the kernel CHECKS (running
-// min/max).  For 8/12-bit device data honouring its contract the worst-case bound (3.49x per
+// that is exact iff every stage-1 and stage-2 output fits int16, which the kernel CHECKS (OR of
+// y + 0x8000 must stay below 2^16).  For 8/12-bit device data honouring its contract the worst-case bound (3.49x per
 // stage) guarantees it; otherwise the wave raises the overflow flag of every 4096-sample chunk
 // from the failing sub-chunk to the end of its segment and the EXACT kernel (decim_kernel.hpp,
 // int32 arms throughout, launched right behind on the same stream) recomputes exactly those
@@ -214,7 +214,7 @@ void decim_fast_kernel(const void* __restrict__ hist_v,    // DF_CHUNK samples: 
     };
     fetch(first - DF_WARM);
     bool bad = false;
-    int vmin = 0, vmax = 0;                                    // running range of the int16-stored outputs
+    uint32_t ovf_or = 0;                                       // OR of (y + 0x8000) over every int16-stored output so far
     __syncthreads();
 
     for (long sub = first - DF_WARM; sub < last; ++sub) {
@@ -242,12 +242,11 @@ void decim_fast_kernel(const void* __restrict__ hist_v,    // DF_CHUNK samples: 
                 stage_pk16<64, MODE, (s == 1 ? PRE : 0), R>(iI, iQ, jI, jQ, lane, yI, yQ);
                 if constexpr (s < L) {
                     if constexpr (s + 1 <= 3) {
-                        // these outputs are re-read as int16: track their range
+                        // these outputs are re-read as int16: y fits iff (y + 0x8000) has no bit above 15.  add + or
+                        // are full-rate VALU ops on gfx950, v_max/v_min are half rate (profiles/r01_valu_issue_rates.txt)
 #pragma unroll
-                        for (int r = 0; r < R; r += 2) {
-                            vmax = max(vmax, max(max(yI[r], yI[r + 1]), max(yQ[r], yQ[r + 1])));
-                            vmin = min(vmin, min(min(yI[r], yI[r + 1]), min(yQ[r], yQ[r + 1])));
-                        }
+                        for (int r = 0; r < R; r++)
+                            ovf_or |= ((uint32_t)yI[r] + 0x8000u) | ((uint32_t)yQ[r] + 0x8000u);
                         put_pk16<R>(nI, nI + df_arr(s + 1), nI + 2 * df_arr(s + 1), nI + 3 * df_arr(s + 1), lane, yI, yQ);
                     } else {
                         int* d = reinterpret_cast<int*>(nI);
@@ -285,7 +284,7 @@ void decim_fast_kernel(const void* __restrict__ hist_v,    // DF_CHUNK samples: 
 
         // overflow bookkeeping (wave-uniform): any int16-stored output out of range so far?
         if constexpr (L >= 2) {
-            const bool mine = vmax > 32767 || vmin < -32768;
+            const bool mine = (ovf_or >> 16) != 0;
             if (!bad && __any(mine)) bad = true;
         }
         if (live && lane == 0 && ((sub + 1) % (DF_CHUNK / S) == 0 || sub + 1 == last))
