@@ -179,6 +179,24 @@ int sdrx_backend_get_design(sdrx_backend_t* h, int32_t ch, int32_t* ntaps_per_ph
 int sdrx_backend_sync(sdrx_backend_t* h);
 
 /* ------------------------------------------------------------------------------------------
+ * Lowpass<Real> / Bandpass<Real> (sdrbase/dsp/lowpass.h:11-105, bandpass.h:11-128): the symmetric-folded real
+ * FIRs of the demods' audio tail (NFM: m_lowpass.create(301, rate, 250.0), m_bandpass.create(301, rate, 300.0, bw),
+ * nfmdemod.cpp:88,428-429; filter() per audio sample :239,279), N channels per handle, state carried across feeds.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sdrx_firbank sdrx_firbank_t;
+typedef struct sdrx_fir_cfg {
+    int32_t kind;            /* 0: Lowpass::create(ntaps, sample_rate, f1); 1: Bandpass::create(ntaps, sample_rate, f1, f2) */
+    int32_t ntaps;           /* made odd like the reference does */
+    float   sample_rate, f1, f2;
+} sdrx_fir_cfg;
+int sdrx_firbank_create(sdrx_firbank_t** out, int device, int32_t n_ch, const sdrx_fir_cfg* cfg);
+int sdrx_firbank_destroy(sdrx_firbank_t* h);
+/* == filter(sample) for every sample of in[c]; out[c] gets n_per_ch[c] floats */
+int sdrx_firbank_feed(sdrx_firbank_t* h, const float* const* in, const int64_t* n_per_ch, float* const* out);
+/* the ntaps/2 + 1 folded taps (m_taps); returns their count */
+int sdrx_firbank_get_taps(const sdrx_firbank_t* h, int32_t ch, float* taps, int32_t cap);
+
+/* ------------------------------------------------------------------------------------------
  * SampleSinkFifo (sdrbase/dsp/samplesinkfifo.{h,cpp}) -- host ring of `Sample`, same
  * write / readBegin / readCommit contract, minus the Qt signal (a callback instead of dataReady()).
  * ------------------------------------------------------------------------------------------ */

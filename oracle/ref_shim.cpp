@@ -22,6 +22,8 @@
 #include "dsp/interpolator.h"
 #include "dsp/fftfilt.h"
 #include "dsp/phasediscri.h"
+#include "dsp/lowpass.h"
+#include "dsp/bandpass.h"
 
 namespace {
 
@@ -234,6 +236,21 @@ void ref_discri(int kind, float fm_scaling, const float* in_iq, int64_t n, float
         if (kind == 0) { double magsq; Real fmDev; out[i] = d.phaseDiscriminatorDelta(c, magsq, fmDev); }
         else out[i] = d.phaseDiscriminator(c);
     }
+}
+
+// Lowpass<Real> / Bandpass<Real> (lowpass.h, bandpass.h) as NFMDemod uses them (nfmdemod.cpp:88,239,279,428-429)
+struct RefFir { int kind; Lowpass<Real> lp; Bandpass<Real> bp; };
+void* ref_fir_new(int kind, int ntaps, double rate, double f1, double f2)
+{
+    RefFir* f = new RefFir; f->kind = kind;
+    if (kind == 0) f->lp.create(ntaps, rate, f1); else f->bp.create(ntaps, rate, f1, f2);
+    return f;
+}
+void ref_fir_free(void* h) { delete static_cast<RefFir*>(h); }
+void ref_fir_run(void* h, const float* in, int64_t n, float* out)
+{
+    RefFir* f = static_cast<RefFir*>(h);
+    for (int64_t i = 0; i < n; i++) out[i] = f->kind == 0 ? f->lp.filter(in[i]) : f->bp.filter(in[i]);
 }
 
 } // extern "C"

@@ -74,6 +74,13 @@ int64_t sdro_fftfilt_run(sdro_fftfilt*, int32_t mode, const float* in_iq, int64_
 /* kind 0: phaseDiscriminatorDelta (phasediscri.h:61-78); 1: phaseDiscriminator (:50-55) */
 void    sdro_discri(int32_t kind, float fm_scaling, const float* in_iq, int64_t n, float* out);
 
+/* Lowpass<Real> (kind 0: create(ntaps, rate, f1)) / Bandpass<Real> (kind 1: create(ntaps, rate, f1, f2)), lowpass.h / bandpass.h */
+typedef struct sdro_fir sdro_fir;
+sdro_fir* sdro_fir_new(int32_t kind, int32_t ntaps, double rate, double f1, double f2);
+void    sdro_fir_free(sdro_fir*);
+int32_t sdro_fir_taps(const sdro_fir*, float* out);                      /* ntaps/2 + 1 folded taps */
+void    sdro_fir_run(sdro_fir*, const float* in, int64_t n, float* out); /* streaming: state carried */
+
 #ifdef __cplusplus
 }
 #endif

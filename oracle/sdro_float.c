@@ -370,3 +370,68 @@ void sdro_discri(int32_t kind, float fm_scaling, const float* in, int64_t n, flo
         }
     }
 }
+
+/* ------------------------------------------------------------------ Lowpass<Real> / Bandpass<Real> (lowpass.h, bandpass.h)
+ * Tap design restated with the reference's float/double mix; filter() restated from what the ring walk
+ * actually sums (lowpass.h:55-99): with x[n] the newest sample, N taps, h = N/2,
+ *     y[n] = (x[n] + x[n-1]) t[0] + sum_{i=1}^{h-1} (x[n-N+i] + x[n-1-i]) t[i] + x[n-N+h] t[h]
+ * accumulated in that order in float (x[n-N] has just been overwritten by x[n], hence the odd first pair). */
+struct sdro_fir { int N, h; float* t; float* hist; };
+
+sdro_fir* sdro_fir_new(int32_t kind, int32_t ntaps, double rate, double f1, double f2)
+{
+    const double PI = 3.14159265358979323846;
+    if (!(ntaps & 1)) ntaps++;
+    sdro_fir* f = (sdro_fir*)calloc(1, sizeof *f);
+    f->N = ntaps; f->h = ntaps / 2;
+    const int nt = ntaps / 2 + 1;
+    f->t = (float*)calloc((size_t)nt, sizeof(float));
+    f->hist = (float*)calloc((size_t)ntaps, sizeof(float));
+    const double mid = ((double)ntaps - 1.0) / 2.0;
+    if (kind == 0) {                                           /* Lowpass::create (lowpass.h:16-52) */
+        const double Wc = 2.0 * PI * f1 / rate;
+        for (int i = 0; i < nt; i++)
+            f->t[i] = (i == (ntaps - 1) / 2) ? (float)(Wc / PI) : (float)(sin(((double)i - mid) * Wc) / (((double)i - mid) * PI));
+        for (int i = 0; i < nt; i++) f->t[i] = (float)(f->t[i] * (0.54 + 0.46 * cos((2.0 * PI * ((double)i - mid)) / (double)ntaps)));
+    } else {                                                   /* Bandpass::create (bandpass.h:14-75) */
+        const double Wcl = 2.0 * PI * f1 / rate, Wch = 2.0 * PI * f2 / rate;
+        float* lp = (float*)calloc((size_t)nt, sizeof(float)); float* hp = (float*)calloc((size_t)nt, sizeof(float));
+        for (int i = 0; i < nt; i++) {
+            if (i == (ntaps - 1) / 2) { lp[i] = (float)(Wch / PI); hp[i] = (float)(-(Wcl / PI)); }
+            else { lp[i] = (float)(sin(((double)i - mid) * Wch) / (((double)i - mid) * PI)); hp[i] = (float)(-sin(((double)i - mid) * Wcl) / (((double)i - mid) * PI)); }
+        }
+        hp[(ntaps - 1) / 2] += 1;
+        for (int i = 0; i < nt; i++) {
+            const double w = 0.54 + 0.46 * cos((2.0 * PI * ((double)i - mid)) / (double)ntaps);
+            lp[i] = (float)(lp[i] * w); hp[i] = (float)(hp[i] * w);
+            f->t[i] = -(lp[i] + hp[i]);
+        }
+        f->t[(ntaps - 1) / 2] += 1;
+        free(lp); free(hp);
+    }
+    float sum = 0; int i;
+    for (i = 0; i < nt - 1; i++) sum += f->t[i] * 2;
+    sum += f->t[i];
+    for (i = 0; i < nt; i++) f->t[i] /= sum;
+    return f;
+}
+void sdro_fir_free(sdro_fir* f) { if (f) { free(f->t); free(f->hist); free(f); } }
+int32_t sdro_fir_taps(const sdro_fir* f, float* out) { memcpy(out, f->t, sizeof(float) * (size_t)(f->h + 1)); return f->h + 1; }
+
+void sdro_fir_run(sdro_fir* f, const float* in, int64_t n, float* out)
+{
+    const int N = f->N, h = f->h;
+    float* x = (float*)malloc(sizeof(float) * (size_t)(n + N));    /* x[N + k] = in[k]; x[0..N) = history (oldest first) */
+    memcpy(x, f->hist, sizeof(float) * (size_t)N);
+    memcpy(x + N, in, sizeof(float) * (size_t)n);
+    for (int64_t k = 0; k < n; k++) {
+        const float* c = x + N + k;                            /* c[0] = x[n], c[-1] = x[n-1], ... */
+        float acc = 0;
+        acc += (c[0] + c[-1]) * f->t[0];
+        for (int i = 1; i < h; i++) acc += (c[-N + i] + c[-1 - i]) * f->t[i];
+        acc += c[-N + h] * f->t[h];
+        out[k] = acc;
+    }
+    memcpy(f->hist, x + n, sizeof(float) * (size_t)N);
+    free(x);
+}

@@ -98,6 +98,10 @@ def lib() -> C.CDLL:
         "sdrx_backend_read": (i64, [vp, i32, vp, i64]),
         "sdrx_backend_get_design": (C.c_int, [vp, i32, C.POINTER(i32), vp, i32, vp, C.POINTER(i32)]),
         "sdrx_backend_sync": (C.c_int, [vp]),
+        "sdrx_firbank_create": (C.c_int, [pp, C.c_int, i32, vp]),
+        "sdrx_firbank_destroy": (C.c_int, [vp]),
+        "sdrx_firbank_feed": (C.c_int, [vp, vp, vp, vp]),
+        "sdrx_firbank_get_taps": (C.c_int, [vp, i32, vp, i32]),
         "sdrx_sdriq_parse_header": (C.c_int, [vp, C.c_uint64, vp]),
         "sdrx_sdriq_write_header": (C.c_int, [vp, vp]),
         "sdrx_fifo_create": (C.c_int, [pp, u32]),
@@ -312,6 +316,42 @@ class ChannelizerBank:
         g, b, l = C.c_int(), C.c_int(), C.c_int()
         _check(lib().sdrx_chan_bank_last_launch(self._h, name, 128, C.byref(g), C.byref(b), C.byref(l)), "last_launch")
         return {"kernel": name.value.decode(), "grid": g.value, "block": b.value, "lds_bytes": l.value}
+
+
+class FirCfg(C.Structure):
+    """sdrx_fir_cfg"""
+    _fields_ = [("kind", C.c_int32), ("ntaps", C.c_int32), ("sample_rate", C.c_float), ("f1", C.c_float), ("f2", C.c_float)]
+
+
+class FirBank:
+    """Lowpass<Real> / Bandpass<Real> (sdrbase/dsp/lowpass.h, bandpass.h) for N channels."""
+
+    def __init__(self, cfgs, device: int = 0):
+        self.n_ch = len(cfgs)
+        arr = (FirCfg * self.n_ch)(*cfgs)
+        self._h = C.c_void_p()
+        _check(lib().sdrx_firbank_create(C.byref(self._h), device, self.n_ch, arr), "sdrx_firbank_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sdrx_firbank_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def taps(self, ch: int) -> np.ndarray:
+        t = np.zeros(4096, np.float32)
+        n = lib().sdrx_firbank_get_taps(self._h, ch, t.ctypes.data, t.size)
+        return t[:n].copy()
+
+    def feed(self, per_channel):
+        ins = [np.ascontiguousarray(x, dtype=np.float32) for x in per_channel]
+        outs = [np.empty(max(x.size, 1), np.float32) for x in ins]
+        pi = (C.c_void_p * self.n_ch)(*[x.ctypes.data for x in ins])
+        po = (C.c_void_p * self.n_ch)(*[x.ctypes.data for x in outs])
+        ns = (C.c_int64 * self.n_ch)(*[x.size for x in ins])
+        _check(lib().sdrx_firbank_feed(self._h, pi, ns, po), "sdrx_firbank_feed")
+        return [o[: x.size] for o, x in zip(outs, ins)]
 
 
 class SdriqHeader(C.Structure):

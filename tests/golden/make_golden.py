@@ -188,6 +188,14 @@ def main():
         o = np.zeros(y.size // 2, np.float32)
         ref.ref_discri(kind, 24.0, y.ctypes.data, y.size // 2, o.ctypes.data)
         fl[f"discri_{nm}"] = o
+    # audio FIRs of the NFM tail (nfmdemod.cpp:428-429) on the discriminator output
+    ref.ref_fir_new.restype = vp; ref.ref_fir_new.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
+    ref.ref_fir_run.argtypes = [vp, vp, i64, vp]
+    d = np.ascontiguousarray(fl["discri_delta"])
+    for kind, nm, a, b in ((0, "lowpass301", 250.0, 0.0), (1, "bandpass301", 300.0, 3000.0)):
+        h = ref.ref_fir_new(kind, 301, 48000.0, a, b); o = np.zeros(d.size, np.float32)
+        ref.ref_fir_run(h, d.ctypes.data, d.size, o.ctypes.data)
+        fl[nm] = o
     np.savez_compressed(os.path.join(HERE, "float_golden.npz"), **fl)
     print("golden written:", sorted(os.listdir(HERE)))
 

@@ -53,6 +53,29 @@ def _sig_float(L):
     L.sdro_discri.argtypes = [i32, f32, vp, i64, vp]
 
 
+class Fir:
+    """oracle Lowpass (kind 0) / Bandpass (kind 1), streaming"""
+
+    def __init__(self, kind, ntaps, rate, f1, f2=0.0):
+        L = lib()
+        L.sdro_fir_new.restype = C.c_void_p; L.sdro_fir_new.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]
+        L.sdro_fir_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.sdro_fir_taps.restype = C.c_int32; L.sdro_fir_taps.argtypes = [C.c_void_p, C.c_void_p]
+        self.L = L
+        self.h = L.sdro_fir_new(kind, ntaps, rate, f1, f2)
+
+    def taps(self):
+        t = np.zeros(4096, np.float32)
+        n = self.L.sdro_fir_taps(self.h, t.ctypes.data)
+        return t[:n].copy()
+
+    def run(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty(max(x.size, 1), np.float32)
+        self.L.sdro_fir_run(self.h, x.ctypes.data, x.size, out.ctypes.data)
+        return out[: x.size].copy()
+
+
 class Backend:
     """oracle of one channel's NCO -> Interpolator -> [fftfilt] -> [discriminator] chain, streaming"""
 

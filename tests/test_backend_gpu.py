@@ -130,3 +130,20 @@ def test_cfg4_pipeline_bank_to_backend_on_device():
             assert got.size == want.size, (c, got.size, want.size)
             assert ulp_diff(got, want) == 0, c
             bank.skip(c)
+
+
+def test_audio_fir_bank_lowpass_bandpass():
+    """a14: Lowpass<Real>/Bandpass<Real> as NFM uses them (301 taps @ 48 kS/s: 250 Hz CTCSS low pass, 300..3000 Hz audio
+    band pass) + odd corner sizes; streaming with ragged feeds; taps and outputs bit-identical to the oracle"""
+    specs = [(0, 301, 48000.0, 250.0, 0.0), (1, 301, 48000.0, 300.0, 3000.0), (0, 64, 48000.0, 3000.0, 0.0), (1, 21, 8000.0, 300.0, 2500.0)]
+    bank = sa.FirBank([sa.FirCfg(k, n, r, a, b) for k, n, r, a, b in specs])
+    oras = [orc.Fir(k, n, r, a, b) for k, n, r, a, b in specs]
+    for c, o in enumerate(oras):
+        assert np.array_equal(bank.taps(c).view(np.uint32), o.taps().view(np.uint32)), c
+    rng = np.random.default_rng(11)
+    for sizes in ([1, 0, 5, 3], [1000, 17, 0, 400], [4801, 4801, 4801, 4801], [0, 0, 0, 0]):
+        xs = [rng.standard_normal(n).astype(np.float32) for n in sizes]
+        got = bank.feed(xs)
+        for c, o in enumerate(oras):
+            want = o.run(xs[c])
+            assert got[c].size == want.size and np.array_equal(got[c].view(np.uint32), want.view(np.uint32)), (c, sizes)

@@ -46,6 +46,9 @@ def test_float_oracle_vs_reference_vectors():
     y = np.ascontiguousarray(g["fftfilt_usb"])
     o = np.zeros(y.size // 2, np.float32); L.sdro_discri(0, 24.0, y.ctypes.data, y.size // 2, o.ctypes.data)
     assert np.array_equal(bits(o), bits(g["discri_delta"]))
+    dd = np.ascontiguousarray(g["discri_delta"])
+    assert np.array_equal(bits(orc.Fir(0, 301, 48000.0, 250.0).run(dd)), bits(g["lowpass301"]))
+    assert np.array_equal(bits(orc.Fir(1, 301, 48000.0, 300.0, 3000.0).run(dd)), bits(g["bandpass301"]))
     o = np.zeros(y.size // 2, np.float32); L.sdro_discri(1, 24.0, y.ctypes.data, y.size // 2, o.ctypes.data)
     assert np.max(np.abs(o - g["discri_atan2"])) <= 1e-5        # atan2f: same libm here, but do not rely on it
 

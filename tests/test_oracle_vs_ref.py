@@ -120,3 +120,17 @@ def test_qt_adapter_compiles_against_reference_headers():
     so = os.path.join(ROOT, "oracle", "_ref", "libsdrx_qt_adapter.so")
     syms = subprocess.check_output(["nm", "-DC", "--defined-only", so], text=True)
     assert "GpuDownChannelizerBank::feed" in syms and "GpuDownChannelizerBank::handleMessage" in syms
+
+
+def test_audio_firs_vs_reference():
+    """Lowpass<Real> / Bandpass<Real> (lowpass.h, bandpass.h): taps design + the ring walk of filter(), bit for bit"""
+    L = C.CDLL(REF)
+    L.ref_fir_new.restype = C.c_void_p; L.ref_fir_new.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
+    L.ref_fir_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    rng = np.random.default_rng(3)
+    for kind, nt, rate, f1, f2 in ((0, 301, 48000.0, 250.0, 0.0), (1, 301, 48000.0, 300.0, 3000.0), (0, 64, 48000.0, 3000.0, 0.0), (1, 21, 8000.0, 300.0, 2500.0)):
+        hr = L.ref_fir_new(kind, nt, rate, f1, f2); o = orc.Fir(kind, nt, rate, f1, f2)
+        for n in (1, 7, 1000, 0, 5000):
+            x = rng.standard_normal(n).astype(np.float32); A = np.zeros(n + 1, np.float32)
+            L.ref_fir_run(hr, x.ctypes.data, n, A.ctypes.data)
+            assert np.array_equal(A[:n].view(np.uint32), o.run(x).view(np.uint32)), (kind, nt, n)
