@@ -206,9 +206,7 @@ def main():
         def step():
             h.feed_dev(x.data_ptr(), B)
             if be is not None:
-                ptrs, cnts = zip(*[h.last_dev(c) for c in range(n_ch)])
-                h.sync()                         # the back-end runs on its own stream
-                be.feed_dev(ptrs, cnts)
+                be.feed_bank(h)                  # device-ordered hand-over; the back-end runs on its own stream
                 be.sync()
             for c in range(n_ch):               # consumer side: drop the queued outputs (host bookkeeping only)
                 h.skip(c)

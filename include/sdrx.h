@@ -135,6 +135,8 @@ int64_t sdrx_chan_bank_skip(sdrx_chan_bank_t* h, int32_t ch, int64_t n);
 int sdrx_chan_bank_last_dev(sdrx_chan_bank_t* h, int32_t ch, const int16_t** d_out_iq, int64_t* n_cplx);
 int sdrx_chan_bank_sync(sdrx_chan_bank_t* h);
 int sdrx_chan_bank_set_stream(sdrx_chan_bank_t* h, void* hip_stream);
+/* the hipStream_t the bank's kernels run on (its own stream unless set_stream gave it another) */
+int sdrx_chan_bank_get_stream(sdrx_chan_bank_t* h, void** hip_stream);
 /* as sdrx_decim_set_timing: brackets each feed's tree_kernel launches (all passes) */
 int sdrx_chan_bank_set_timing(sdrx_chan_bank_t* h, int enabled);
 int sdrx_chan_bank_get_timing(sdrx_chan_bank_t* h, double* total_ms, int64_t* feeds, int reset);
@@ -169,6 +171,11 @@ int sdrx_backend_destroy(sdrx_backend_t* h);
 /* iq[c] / n_per_ch[c]: channel c's new samples (what DownChannelizer handed to m_sampleSink->feed) */
 int sdrx_backend_feed(sdrx_backend_t* h, const int16_t* const* iq, const int64_t* n_per_ch);
 int sdrx_backend_feed_dev(sdrx_backend_t* h, const int16_t* const* d_iq, const int64_t* n_per_ch);
+/* cfg 4 hand-over without a host round trip: channel c takes what the bank's last feed produced for its channel c
+ * (sdrx_chan_bank_last_dev), ordered on the device -- the back-end's readers wait for the bank's stream, and the bank's
+ * stream waits until they have consumed the samples before anything queued on it later (its next feed) may run.
+ * The distance schedule, which needs the counts only, overlaps the bank's kernels. */
+int sdrx_backend_feed_bank(sdrx_backend_t* h, sdrx_chan_bank_t* bank);
 /* outputs of the last feed for channel ch: complex (re,im pairs) unless a discriminator is on;
  * returns the number of FLOATS written (<0: error) */
 int64_t sdrx_backend_read(sdrx_backend_t* h, int32_t ch, float* out, int64_t cap_floats);

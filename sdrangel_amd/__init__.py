@@ -88,6 +88,7 @@ def lib() -> C.CDLL:
         "sdrx_chan_bank_last_dev": (C.c_int, [vp, i32, pp, C.POINTER(i64)]),
         "sdrx_chan_bank_sync": (C.c_int, [vp]),
         "sdrx_chan_bank_set_stream": (C.c_int, [vp, vp]),
+        "sdrx_chan_bank_get_stream": (C.c_int, [vp, C.POINTER(vp)]),
         "sdrx_chan_bank_set_timing": (C.c_int, [vp, C.c_int]),
         "sdrx_chan_bank_get_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i64), C.c_int]),
         "sdrx_chan_bank_last_launch": (C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -95,6 +96,7 @@ def lib() -> C.CDLL:
         "sdrx_backend_destroy": (C.c_int, [vp]),
         "sdrx_backend_feed": (C.c_int, [vp, vp, vp]),
         "sdrx_backend_feed_dev": (C.c_int, [vp, vp, vp]),
+        "sdrx_backend_feed_bank": (C.c_int, [vp, vp]),
         "sdrx_backend_read": (i64, [vp, i32, vp, i64]),
         "sdrx_backend_get_design": (C.c_int, [vp, i32, C.POINTER(i32), vp, i32, vp, C.POINTER(i32)]),
         "sdrx_backend_sync": (C.c_int, [vp]),
@@ -403,6 +405,10 @@ class BackendBank:
         ptrs = (C.c_void_p * self.n_ch)(*[b.ctypes.data for b in bufs])
         ns = (C.c_int64 * self.n_ch)(*[b.size // 2 for b in bufs])
         _check(lib().sdrx_backend_feed(self._h, ptrs, ns), "sdrx_backend_feed")
+
+    def feed_bank(self, bank: "ChannelizerBank"):
+        """channel c takes what the bank's last feed produced for its channel c; ordered on the device, no host sync"""
+        _check(lib().sdrx_backend_feed_bank(self._h, bank._h), "sdrx_backend_feed_bank")
 
     def feed_dev(self, ptrs, counts):
         p = (C.c_void_p * self.n_ch)(*ptrs)

@@ -53,7 +53,7 @@ struct BeBufs {                         // per channel device pointers (per feed
     uint32_t* hist;                     // BE_HIST packed Samples: tail of the previous feeds
     uint32_t* hist_next;
     float2* mixed;                      // BE_HIST + n_in: NCO-mixed samples, index BE_HIST + k
-    uint32_t* sched;                    // per resampler output o: sched[o * sched_stride] = k * 16 + phase (channel-interleaved
+    uint2* sched;                       // per resampler output o: sched[o * sched_stride] = {k, bits(distance)} (channel-interleaved
                                         // so that the serial schedule lanes of a wave store to neighbouring addresses)
     float2* res;                        // [pending | new resampler outputs]
     float2* head;                       // n_blocks * 512
@@ -64,40 +64,76 @@ struct BeBufs {                         // per channel device pointers (per feed
     long sched_stride;                  // = number of channels
 };
 
-// ---- 1. schedule: the float `distance` recurrence, one lane per channel (serial by nature).
+// ---- 1. schedule: the float `distance` recurrence, one lane per channel (serial by nature; 256 channels = 4 waves, so the
+// kernel's time is instructions-per-emission x single-wave issue latency -- the loop body is kept to the recurrence itself).
 // Walks emission by emission instead of input by input: while d >= 1 the reference's `d -= 1.0` is exact, so
 // after an emission leaves d_new the next one happens m = max(1, floor(d_new)) inputs later with
 // d = d_new - m (exact) -- or fl(d_new - 1) when d_new < 1 -- which is bit-for-bit what the per-input loop holds.
-__global__ void be_schedule_kernel(BeChan* __restrict__ ch, const BeBufs* __restrict__ bufs, int n_ch)
+// Entry o of a channel = {k, bits(d)}: k = index of the input that completes the emission, d = the distance the
+// reference passes to doInterpolate(); the FIR kernel derives the phase floor(d * phase_steps) from it.
+// Unchecked batches: once one emission has happened d_post < 1, so every later emission consumes
+// m <= M = max(1, floor(fl(1 + step))) inputs; with R inputs left, the next R / M emissions cannot run past the
+// feed and need no end test.  The wave runs min-over-lanes(R / M) of them with a scalar trip count, re-evaluates,
+// and finishes the last few emissions of each lane in the checked loop.
+struct BeSchedLane {
+    float d; int k; uint2* p;
+};
+__device__ __forceinline__ void be_sched_emit(BeSchedLane& l, const float step, const long stride)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_ch) return;
+    const float m_f = fmaxf(floorf(l.d), 1.0f);             // inputs until the next emission: floor(d) if d >= 1, else 1
+    l.k += (int)m_f;
+    l.d -= m_f;                                             // d - floor(d) is exact; d - 1.0f is the reference's own op when d < 1
+    *l.p = make_uint2((uint32_t)l.k, __float_as_uint(l.d));
+    l.p += stride;
+    l.d += step;
+}
+__device__ __forceinline__ int be_wave_min(int v)
+{
+    for (int o = 32; o; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__global__ void __launch_bounds__(64) be_schedule_kernel(BeChan* __restrict__ ch, const BeBufs* __restrict__ bufs, const int* __restrict__ perm, int n_ch)
+{
+    const int c_raw = blockIdx.x * 64 + threadIdx.x;       // = schedule column; perm[column] = channel (columns are sorted by filter design)
+    const int c = perm[c_raw < n_ch ? c_raw : n_ch - 1];   // surplus lanes shadow the last column (same values to the same addresses)
     BeChan& s = ch[c];
-    uint32_t* sched = bufs[c].sched;
     const long stride = bufs[c].sched_stride;
-    const int n_in = (int)bufs[c].n_in;
-    s.n_in = n_in;
-    float d = s.distance;                                   // value BEFORE the next input's `-= 1.0`
-    const float step = s.step, ps = (float)s.phase_steps;
-    int cnt = 0;
-    long k = -1;                                            // index of the last consumed input
+    const int n_in = (int)bufs[c].n_in;                     // < 2^28
+    const float step = s.step;
+    BeSchedLane l; l.d = s.distance; l.k = -1; l.p = bufs[c].sched;     // d: value BEFORE the next input's `-= 1.0`
+    uint2* const p0 = l.p;
+    const int M = max(1, (int)fminf(floorf(1.0f + step), 1.0e6f));
+    bool first = true;
     for (;;) {
-        // inputs until the next emission
-        const int m = d >= 1.0f ? (int)floorf(d) : 1;
-        if (k + m >= n_in) {                                // the feed ends first: consume what is left, no emission
-            const int left = (int)(n_in - 1 - k);           // inputs still to consume (each: d -= 1, all stay >= 1 or it would emit)
-            d = d - (float)left;                            // exact: d - left >= 1 unless left == 0
-            break;
+        // checked emissions: always the first of a feed (the carried-in d is not bounded by M), then whatever the batches left
+        int budget = first ? 1 : 0x7fffffff;
+        bool done = false;
+        while (budget-- > 0) {
+            const int kn = l.k + (int)fmaxf(floorf(l.d), 1.0f);
+            if (kn >= n_in) { done = true; break; }
+            be_sched_emit(l, step, stride);
         }
-        k += m;
-        d = d >= 1.0f ? d - (float)m : d - 1.0f;
-        int ph = (int)floorf(d * ps);
-        if (ph < 0) ph = 0;
-        sched[(long)cnt * stride] = (uint32_t)k * 16u + (uint32_t)ph;
-        cnt++;
-        d = d + step;
+        if (!first) break;
+        first = false;
+        // unchecked batches
+        for (;;) {
+            const int safe = done ? 0 : (n_in - 1 - l.k) / M;
+            const bool parked = safe < 16;                  // nearly finished lanes sit out and do not hold the others back
+            const int wave_safe = be_wave_min(parked ? 0x7fffffff : safe);
+            if (wave_safe == 0x7fffffff) break;
+            if (!parked) {
+                for (int i = wave_safe >> 2; i > 0; --i) {
+                    be_sched_emit(l, step, stride); be_sched_emit(l, step, stride);
+                    be_sched_emit(l, step, stride); be_sched_emit(l, step, stride);
+                }
+            }
+        }
+        if (done) break;
     }
-    s.distance = d;
+    if (c_raw >= n_ch) return;
+    s.n_in = n_in;
+    s.distance = l.d - (float)(n_in - 1 - l.k);             // inputs consumed without an emission: each `-= 1.0` exact (d stays >= 1)
+    const int cnt = (int)((l.p - p0) / stride);
     s.n_res = cnt;
     s.n_blocks = s.filt_mode ? (s.pending + cnt) / s.half : 0;
 }
@@ -120,29 +156,117 @@ __global__ void be_mix_kernel(const BeChan* __restrict__ ch, const BeBufs* __res
         float2 m; m.x = a * o_r - q * o_i; m.y = a * o_i + q * o_r;         // std::complex<float> operator*=
         b.mixed[i] = m;
     }
+    // raw history for the next feed: last BE_HIST of (old history ++ new input); double-buffered, so nothing read here is overwritten
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < BE_HIST; i += blockDim.x) {
+            const long src = (long)i + s.n_in - BE_HIST;
+            b.hist_next[i] = src >= 0 ? b.in[src] : b.hist[i + s.n_in];
+        }
+    }
 }
 
-// ---- 2b. polyphase FIR, one lane per output, taps summed newest-first like the ring walk
-__global__ void be_fir_kernel(const BeChan* __restrict__ ch, const BeBufs* __restrict__ bufs, const float* __restrict__ taps)
+// ---- 2b. polyphase FIR, one lane per output, taps summed newest-first like the ring walk (mul and add separate, in order).
+// The schedule is column-interleaved (entry o of column q at [o * n_ch + q]; perm[q] = channel, columns sorted by
+// interpolator design), so a workgroup takes a tile of 64 outputs x 16 columns: 128-byte rows in, transposed through
+// LDS; each wave then walks 4 columns with its 64 lanes on 64 consecutive outputs of one channel.
+// Interpolator::create's "taps per phase" argument 4.5 yields 72 taps per phase (interpolator.cpp: ntaps =
+// (int)(4.5 * 16), then * 16 phases), so an output is 72 complex-by-real MACs: the 16 x nt tap table (odd pitch) is
+// staged in LDS once per workgroup -- channels with the same design share one table (the host de-duplicates them and
+// the column order keeps them together) -- and each wave stages the input window [kmin - nt + 1, kmax] of its 64
+// outputs; the tap loop runs from LDS.  A tile that straddles two designs reads its taps from global memory, and a
+// window that does not fit is read from global memory, with the same loop.  After the tile barrier the waves are
+// independent (wave-private windows, wave-level ordering only), so one wave's staging latency overlaps the others' taps.
+constexpr int BE_FIR_TO = 64, BE_FIR_TC = 16;
+constexpr int BE_FIR_XCAP = 384;                            // float2 per wave: 64 * (inputs per output) + nt
+constexpr int BE_FIR_NT_MAX = 80, BE_FIR_TCAP = 16 * (BE_FIR_NT_MAX + 1);
+__device__ __forceinline__ void be_wave_sync()
 {
-    const int c = blockIdx.y;
-    const BeChan s = ch[c];
-    const BeBufs b = bufs[c];
-    const bool direct = s.filt_mode == 0 && s.discri == 0;
-    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < s.n_res; o += gridDim.x * blockDim.x) {
-        const uint32_t e = b.sched[(long)o * b.sched_stride];
-        const int k = (int)(e >> 4), ph = (int)(e & 15u);
-        const float* t = taps + s.taps_off + ph * s.ntaps;
-        const float2* x = b.mixed + BE_HIST + k;
-        float ra = 0.0f, ia = 0.0f;
-        for (int i = 0; i < s.ntaps; i++) {
-            const float2 v = x[-i];
-            ra += t[i] * v.x;
-            ia += t[i] * v.y;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <bool XL, bool TL>                                 // input window / tap table in LDS
+__device__ __forceinline__ float2 be_fir_taps(const float2* x, const float* t, int nt)
+{
+    float ra = 0.0f, ia = 0.0f;
+#pragma unroll 8
+    for (int i = 0; i < nt; i++) {
+        const float2 v = x[-i];
+        ra += t[i] * v.x;
+        ia += t[i] * v.y;
+    }
+    float2 r; r.x = ra; r.y = ia;
+    return r;
+}
+__global__ void __launch_bounds__(256) be_fir_kernel(const BeChan* __restrict__ ch, const BeBufs* __restrict__ bufs,
+                                                     const float* __restrict__ taps, const int* __restrict__ perm, int n_ch)
+{
+    __shared__ uint2 tile[BE_FIR_TO][BE_FIR_TC + 1];
+    __shared__ float2 xw_all[4][BE_FIR_XCAP];
+    __shared__ float tw[BE_FIR_TCAP];
+    const int o0 = blockIdx.x * BE_FIR_TO, q0 = blockIdx.y * BE_FIR_TC;
+    const int q_end = min(q0 + BE_FIR_TC, n_ch);
+    int n_res_max = 0;
+    const BeChan& first = ch[perm[q0]];
+    const int nt0 = first.ntaps, off0 = first.taps_off;
+    bool shared = nt0 <= BE_FIR_NT_MAX;
+    for (int q = q0; q < q_end; q++) {
+        const BeChan& s = ch[perm[q]];
+        n_res_max = max(n_res_max, s.n_res);
+        shared = shared && s.taps_off == off0 && s.ntaps == nt0 && s.phase_steps == 16;
+    }
+    if (o0 >= n_res_max) return;                            // uniform
+    const uint2* __restrict__ sched = bufs[perm[0]].sched;  // bank-wide base (column 0)
+    for (int i = threadIdx.x; i < BE_FIR_TO * BE_FIR_TC; i += 256) {
+        const int row = i / BE_FIR_TC, col = i % BE_FIR_TC;
+        if (q0 + col < n_ch && o0 + row < n_res_max) tile[row][col] = sched[(long)(o0 + row) * n_ch + q0 + col];
+    }
+    if (shared) {
+        const int pitch = nt0 | 1;
+        const float* tg = taps + off0;
+        for (int q = threadIdx.x >> 6; q < 16; q += 4)
+            for (int i = threadIdx.x & 63; i < nt0; i += 64) tw[q * pitch + i] = tg[q * nt0 + i];
+    }
+    __syncthreads();
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    float2* const xw = xw_all[w];
+    const int o = o0 + lane;
+    for (int j = 0; j < BE_FIR_TC / 4; j++) {
+        const int col = w * (BE_FIR_TC / 4) + j;
+        if (q0 + col >= n_ch) break;                        // wave-uniform
+        const int c = perm[q0 + col];
+        const BeChan& s = ch[c];
+        const BeBufs& b = bufs[c];
+        const int n_res = s.n_res;
+        if (o0 >= n_res) continue;                          // wave-uniform
+        const bool valid = o < n_res;
+        const uint2 e = tile[lane][col];
+        const int k = valid ? (int)e.x : 0;
+        int ph = (int)floorf(__uint_as_float(e.y) * (float)s.phase_steps);     // Interpolator::decimate's phase (interpolator.h:33)
+        ph = valid && ph > 0 ? ph : 0;
+        const int nt = s.ntaps;
+        int kmin = valid ? k : 0x7fffffff, kmax = valid ? k : -0x7fffffff;
+        for (int d = 32; d; d >>= 1) { kmin = min(kmin, __shfl_xor(kmin, d, 64)); kmax = max(kmax, __shfl_xor(kmax, d, 64)); }
+        kmin = __builtin_amdgcn_readfirstlane(kmin); kmax = __builtin_amdgcn_readfirstlane(kmax);
+        const int win = kmax - kmin + nt;
+        const bool x_lds = win <= BE_FIR_XCAP;
+        const float* tg = taps + s.taps_off + ph * nt;
+        const float* tl = tw + ph * (nt | 1);
+        const float2* xg = b.mixed + BE_HIST;
+        if (x_lds) {
+            const float2* src = xg + (kmin - nt + 1);
+            for (int i = lane; i < win; i += 64) xw[i] = src[i];
         }
-        float2 r; r.x = ra; r.y = ia;
-        b.res[s.pending + o] = r;
-        if (direct) b.cplx_out[o] = r;
+        be_wave_sync();
+        if (valid) {
+            const float2* xl = xw + (k - kmin) + (nt - 1);
+            float2 r;
+            if (x_lds) r = shared ? be_fir_taps<true, true>(xl, tl, nt) : be_fir_taps<true, false>(xl, tg, nt);
+            else       r = shared ? be_fir_taps<false, true>(xg + k, tl, nt) : be_fir_taps<false, false>(xg + k, tg, nt);
+            b.res[s.pending + o] = r;
+            if (s.filt_mode == 0 && s.discri == 0) b.cplx_out[o] = r;
+        }
+        be_wave_sync();                                     // the next column's staging overwrites xw
     }
 }
 
@@ -326,11 +450,6 @@ void be_carry_kernel(BeChan* __restrict__ ch, const BeBufs* __restrict__ bufs)
         if (!s.filt_mode) v = b.res[pending + n - 1];
         else { const float2 o = b.tail[n - 1], h = b.head[n - 1]; v.x = o.x + h.x; v.y = o.y + h.y; }
         prev_arg = atan2_approx2(v.y, v.x); m1r = v.x; m1i = v.y;
-    }
-    // raw history: last BE_HIST of (old history ++ new input)
-    for (int i = tid; i < BE_HIST; i += 256) {
-        const long src = (long)i + n_in - BE_HIST;
-        b.hist_next[i] = src >= 0 ? b.in[src] : b.hist[i + n_in];
     }
     // fftfilt: unconsumed resampler outputs move to the front; ovlbuf = tail of the last block
     const int left = s.filt_mode ? (pending + n_res) - nb * H : 0;

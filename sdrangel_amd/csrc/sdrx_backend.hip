@@ -82,11 +82,14 @@ struct sdrx_backend {
     int64_t sched_cap = 0;        // entries per channel
     BeBufs* h_bufs = nullptr;     // pinned: the per-feed table goes to the device in one async copy
     hipEvent_t bufs_ev = nullptr; // recorded behind that copy; waited on before the table is rewritten
+    hipEvent_t prod_ev = nullptr, cons_ev = nullptr;       // device-side ordering against a producer stream (sdrx_backend_feed_bank)
     float* d_nco = nullptr; float* d_taps = nullptr; float2* d_filters = nullptr;
     float* d_utbl = nullptr; float* d_utbl2 = nullptr;     // g_fft cosine tables for N = 1024 / 2048
     bool any1024 = false, any2048 = false;
     std::vector<float> taps_all; std::vector<float> filters_all;     // kept for inspection (tests)
     std::vector<int> taps_off, filt_off, ntaps;
+    std::vector<int> perm, col_of;    // schedule column q holds channel perm[q]; col_of[c] is its inverse
+    int* d_perm = nullptr;
     bool state_valid = false;     // d_chan state initialised
 };
 
@@ -140,8 +143,11 @@ int sdrx_backend_destroy(sdrx_backend_t* b)
     if (b->d_bufs) (void)hipFree(b->d_bufs);
     if (b->h_bufs) (void)hipHostFree(b->h_bufs);
     if (b->bufs_ev) (void)hipEventDestroy(b->bufs_ev);
+    if (b->prod_ev) (void)hipEventDestroy(b->prod_ev);
+    if (b->cons_ev) (void)hipEventDestroy(b->cons_ev);
     if (b->d_nco) (void)hipFree(b->d_nco);
     if (b->d_taps) (void)hipFree(b->d_taps);
+    if (b->d_perm) (void)hipFree(b->d_perm);
     if (b->d_filters) (void)hipFree(b->d_filters);
     if (b->d_utbl) (void)hipFree(b->d_utbl);
     if (b->d_utbl2) (void)hipFree(b->d_utbl2);
@@ -197,10 +203,21 @@ int sdrx_backend_create(sdrx_backend_t** out, int device, int32_t n_ch, const sd
         const sdrx_backend_cfg& k = cfg[c];
         ChanHost& h = b->ch[(size_t)c];
         h.cfg = k;
-        std::vector<float> poly; int nt = 0;
-        design_interp(16, (double)k.in_rate, (double)k.interp_cutoff, (double)k.taps_per_phase, poly, &nt);
-        b->taps_off[(size_t)c] = (int)b->taps_all.size(); b->ntaps[(size_t)c] = nt;
-        b->taps_all.insert(b->taps_all.end(), poly.begin(), poly.end());
+        // channels with the same Interpolator::create arguments share one tap table
+        int same = -1;
+        for (int p = 0; p < c && same < 0; p++) {
+            const sdrx_backend_cfg& o = cfg[p];
+            if (o.in_rate == k.in_rate && o.interp_cutoff == k.interp_cutoff && o.taps_per_phase == k.taps_per_phase) same = p;
+        }
+        if (same >= 0) {
+            b->taps_off[(size_t)c] = b->taps_off[(size_t)same]; b->ntaps[(size_t)c] = b->ntaps[(size_t)same];
+        } else {
+            std::vector<float> poly; int nt = 0;
+            design_interp(16, (double)k.in_rate, (double)k.interp_cutoff, (double)k.taps_per_phase, poly, &nt);
+            b->taps_off[(size_t)c] = (int)b->taps_all.size(); b->ntaps[(size_t)c] = nt;
+            b->taps_all.insert(b->taps_all.end(), poly.begin(), poly.end());
+        }
+        const int nt = b->ntaps[(size_t)c];
         b->filt_off[(size_t)c] = c * BE_FFT_MAX;
         const int flen = k.filt_mode == 4 ? BE_FFT_MAX : BE_FFT;
         if (k.filt_mode) {
@@ -248,6 +265,13 @@ int sdrx_backend_create(sdrx_backend_t** out, int device, int32_t n_ch, const sd
             BE_TRY(hipMemset(h.hist[i], 0, BE_HIST * 4));
         }
     }
+    // schedule columns: channels sorted by tap table, so that a FIR tile of 16 columns normally sees one design
+    b->perm.resize((size_t)n_ch); b->col_of.resize((size_t)n_ch);
+    for (int c = 0; c < n_ch; c++) b->perm[(size_t)c] = c;
+    std::stable_sort(b->perm.begin(), b->perm.end(), [&](int x, int y) { return b->taps_off[(size_t)x] < b->taps_off[(size_t)y]; });
+    for (int q = 0; q < n_ch; q++) b->col_of[(size_t)b->perm[(size_t)q]] = q;
+    BE_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_perm), (size_t)n_ch * sizeof(int)));
+    BE_TRY(hipMemcpy(b->d_perm, b->perm.data(), (size_t)n_ch * sizeof(int), hipMemcpyHostToDevice));
     BE_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_taps), b->taps_all.size() * 4));
     BE_TRY(hipMemcpy(b->d_taps, b->taps_all.data(), b->taps_all.size() * 4, hipMemcpyHostToDevice));
     BE_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_chan), (size_t)n_ch * sizeof(BeChan)));
@@ -255,25 +279,33 @@ int sdrx_backend_create(sdrx_backend_t** out, int device, int32_t n_ch, const sd
     BE_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_bufs), (size_t)n_ch * sizeof(BeBufs), hipHostMallocDefault));
     BE_TRY(hipEventCreateWithFlags(&b->bufs_ev, hipEventDisableTiming));
     BE_TRY(hipEventRecord(b->bufs_ev, b->stream));
+    BE_TRY(hipEventCreateWithFlags(&b->prod_ev, hipEventDisableTiming));
+    BE_TRY(hipEventCreateWithFlags(&b->cons_ev, hipEventDisableTiming));
     BE_TRY(hipMemcpy(b->d_chan, b->h_chan.data(), (size_t)n_ch * sizeof(BeChan), hipMemcpyHostToDevice));
 #undef BE_TRY
     *out = b;
     return SDRX_OK;
 }
 
-static int feed_common(sdrx_backend* b, const int16_t* const* d_iq, const int64_t* n_per_ch)
+// producer != nullptr: the input samples are being written on that stream.  The schedule kernel (needs the counts only) is
+// launched first and overlaps the producer; the readers of `in` (be_mix: NCO mix + raw history) wait for the producer on the
+// device, and the producer's stream waits until they are done before it may run anything queued after this call.
+static int feed_common(sdrx_backend* b, const int16_t* const* d_iq, const int64_t* n_per_ch, hipStream_t producer = nullptr)
 {
-    int64_t n_max = 0;
+    int64_t n_max = 0, n_res_bound = 0;
     for (int c = 0; c < b->n_ch; c++) {
         if (n_per_ch[c] < 0 || n_per_ch[c] > 0x0fffffff) { set_error("sdrx_backend_feed: bad length"); return SDRX_EINVAL; }
         int rc = ensure_capacity(b, c, std::max<int64_t>(n_per_ch[c], 1)); if (rc) return rc;
         n_max = std::max(n_max, n_per_ch[c]);
+        // every resampler output after the first two of a stream consumes >= floor(step) inputs (distance >= step before the `-= 1` walk)
+        const int64_t per_out = std::max<int64_t>(1, (int64_t)std::floor(b->h_chan[(size_t)c].step));
+        n_res_bound = std::max(n_res_bound, n_per_ch[c] / per_out + 4);
     }
     if (n_max + 1024 > b->sched_cap) {
         int64_t cap = b->sched_cap ? b->sched_cap : 8192;
         while (cap < n_max + 1024) cap *= 2;
         SDRX_HIP(hipStreamSynchronize(b->stream));
-        int rc = b->sched.reserve((size_t)cap * (size_t)b->n_ch * 4); if (rc) return rc;
+        int rc = b->sched.reserve((size_t)cap * (size_t)b->n_ch * sizeof(uint2)); if (rc) return rc;
         b->sched_cap = cap;
     }
     // per-feed table (pointers + n_in), pinned, one async copy
@@ -283,7 +315,7 @@ static int feed_common(sdrx_backend* b, const int16_t* const* d_iq, const int64_
         BeBufs& u = b->h_bufs[c];
         u.in = reinterpret_cast<const uint32_t*>(d_iq[c]);
         u.hist = h.hist[h.cur]; u.hist_next = h.hist[h.cur ^ 1];
-        u.mixed = static_cast<float2*>(h.mixed.p); u.sched = static_cast<uint32_t*>(b->sched.p) + c; u.sched_stride = b->n_ch;
+        u.mixed = static_cast<float2*>(h.mixed.p); u.sched = static_cast<uint2*>(b->sched.p) + b->col_of[(size_t)c]; u.sched_stride = b->n_ch;
         u.res = static_cast<float2*>(h.res.p); u.head = static_cast<float2*>(h.head.p); u.tail = static_cast<float2*>(h.tail.p);
         u.cplx_out = static_cast<float2*>(h.cplx_out.p); u.real_out = static_cast<float*>(h.real_out.p);
         u.n_in = n_per_ch[c];
@@ -291,11 +323,20 @@ static int feed_common(sdrx_backend* b, const int16_t* const* d_iq, const int64_
     SDRX_HIP(hipMemcpyAsync(b->d_bufs, b->h_bufs, (size_t)b->n_ch * sizeof(BeBufs), hipMemcpyHostToDevice, b->stream));
     SDRX_HIP(hipEventRecord(b->bufs_ev, b->stream));
     const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, (n_max + BE_HIST + 255) / 256));
-    hipLaunchKernelGGL(be_schedule_kernel, dim3((unsigned)((b->n_ch + 63) / 64)), dim3(64), 0, b->stream, b->d_chan, b->d_bufs, b->n_ch);
+    hipLaunchKernelGGL(be_schedule_kernel, dim3((unsigned)((b->n_ch + 63) / 64)), dim3(64), 0, b->stream, b->d_chan, b->d_bufs, b->d_perm, b->n_ch);
     SDRX_HIP(hipGetLastError());
+    if (producer && producer != b->stream) {
+        SDRX_HIP(hipEventRecord(b->prod_ev, producer));
+        SDRX_HIP(hipStreamWaitEvent(b->stream, b->prod_ev, 0));
+    }
     hipLaunchKernelGGL(be_mix_kernel, dim3(gx, (unsigned)b->n_ch), dim3(256), 0, b->stream, b->d_chan, b->d_bufs, b->d_nco);
     SDRX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(be_fir_kernel, dim3(gx, (unsigned)b->n_ch), dim3(256), 0, b->stream, b->d_chan, b->d_bufs, b->d_taps);
+    if (producer && producer != b->stream) {
+        SDRX_HIP(hipEventRecord(b->cons_ev, b->stream));
+        SDRX_HIP(hipStreamWaitEvent(producer, b->cons_ev, 0));
+    }
+    hipLaunchKernelGGL(be_fir_kernel, dim3((unsigned)((n_res_bound + BE_FIR_TO - 1) / BE_FIR_TO), (unsigned)((b->n_ch + BE_FIR_TC - 1) / BE_FIR_TC)), dim3(256), 0,
+                       b->stream, b->d_chan, b->d_bufs, b->d_taps, b->d_perm, b->n_ch);
     SDRX_HIP(hipGetLastError());
     if (b->any1024) {
         const unsigned max_blocks = (unsigned)((n_max + BE_FFT) / (BE_FFT / 2) + 1);
@@ -320,6 +361,21 @@ int sdrx_backend_feed_dev(sdrx_backend_t* b, const int16_t* const* d_iq, const i
     if (!b || !d_iq || !n_per_ch) { set_error("sdrx_backend_feed_dev: null argument"); return SDRX_EINVAL; }
     SDRX_HIP(hipSetDevice(b->device));
     return feed_common(b, d_iq, n_per_ch);
+}
+
+int sdrx_backend_feed_bank(sdrx_backend_t* b, sdrx_chan_bank_t* bank)
+{
+    if (!b || !bank) { set_error("sdrx_backend_feed_bank: null argument"); return SDRX_EINVAL; }
+    SDRX_HIP(hipSetDevice(b->device));
+    void* ps = nullptr;
+    int rc = sdrx_chan_bank_get_stream(bank, &ps); if (rc) return rc;
+    std::vector<const int16_t*> d((size_t)b->n_ch);
+    std::vector<int64_t> n((size_t)b->n_ch);
+    for (int c = 0; c < b->n_ch; c++) {
+        rc = sdrx_chan_bank_last_dev(bank, c, &d[(size_t)c], &n[(size_t)c]);
+        if (rc) { set_error("sdrx_backend_feed_bank: the bank has fewer channels than the back-end"); return rc; }
+    }
+    return feed_common(b, d.data(), n.data(), static_cast<hipStream_t>(ps));
 }
 
 int sdrx_backend_feed(sdrx_backend_t* b, const int16_t* const* iq, const int64_t* n_per_ch)

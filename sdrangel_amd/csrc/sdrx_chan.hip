@@ -697,6 +697,13 @@ int sdrx_chan_bank_sync(sdrx_chan_bank_t* b)
     return SDRX_OK;
 }
 
+int sdrx_chan_bank_get_stream(sdrx_chan_bank_t* b, void** hip_stream)
+{
+    if (!b || !hip_stream) { set_error("sdrx_chan_bank_get_stream: null argument"); return SDRX_EINVAL; }
+    *hip_stream = b->stream;
+    return SDRX_OK;
+}
+
 int sdrx_chan_bank_set_stream(sdrx_chan_bank_t* b, void* hip_stream)
 {
     if (!b) return SDRX_EINVAL;

@@ -35,6 +35,9 @@ CFGS = [
     dict(in_rate=48000, nco_freq=-12000, out_rate=48000, interp_cutoff=10000.0, taps_per_phase=2.0, filt_mode=0, f1=0.0, f2=0.0, discri=1, fm_scaling=5.0),
     # DSB mode of the SSB demod: fftfilt(2*bw/rate, 2048).runDSB (ssbdemod.cpp:92,167)
     dict(in_rate=60000, nco_freq=2500, out_rate=48000, interp_cutoff=6000.0, taps_per_phase=2.0, filt_mode=4, f1=0.0, f2=2 * 3000 / 48000, discri=0, fm_scaling=1.0),
+    # 62500 / 48000 is not a dyadic step: `distance += step` rounds on most emissions (the schedule recurrence must follow the float bits)
+    dict(in_rate=62500, nco_freq=-9100, out_rate=48000, interp_cutoff=12500 / 2.2, taps_per_phase=4.5, filt_mode=0, f1=0.0, f2=0.0, discri=1, fm_scaling=24.0),
+    dict(in_rate=250000, nco_freq=31000, out_rate=44100, interp_cutoff=9000.0, taps_per_phase=4.5, filt_mode=2, f1=300 / 44100, f2=3000 / 44100, discri=0, fm_scaling=1.0),
 ]
 
 
@@ -58,7 +61,7 @@ def test_design_products_match_oracle():
 def test_streaming_feeds_match_oracle():
     pairs = [mk(c) for c in CFGS]
     bank = sa.BackendBank([p[0] for p in pairs])
-    n_total = [40000, 90000, 40000, 30000, 60000, 20000, 25000, 50000]
+    n_total = [40000, 90000, 40000, 30000, 60000, 20000, 25000, 50000, 70001, 131072]
     xs = [synth.mix(n, 700 + i, 12000, 6000, 1 + i % 3) for i, n in enumerate(n_total)]
     # ragged feeds, different per channel, including empty and 1-sample ones
     cut_frac = [0.0, 0.00005, 0.013, 0.013, 0.41, 0.4101, 0.77, 1.0]
@@ -74,6 +77,27 @@ def test_streaming_feeds_match_oracle():
             worst = max(worst, d)
             assert d == 0, (c, a, b, d)
     assert worst == 0
+
+
+def test_many_channels_of_one_design_share_a_tap_table():
+    """40 channels with the same Interpolator design (one tap table, staged once per FIR workgroup), different NCO
+    frequencies and data, plus two odd ones so that one tile of 16 schedule columns straddles two designs."""
+    base = dict(in_rate=60000, out_rate=48000, interp_cutoff=12500 / 2.2, taps_per_phase=4.5, filt_mode=0, f1=0.0, f2=0.0, discri=0, fm_scaling=1.0)
+    cfgs = [dict(base, nco_freq=-7000 + 350 * i) for i in range(40)]
+    cfgs.insert(5, dict(base, in_rate=120000, nco_freq=100))
+    cfgs.insert(23, dict(base, interp_cutoff=4000.0, nco_freq=-100))
+    pairs = [mk(c) for c in cfgs]
+    bank = sa.BackendBank([p[0] for p in pairs])
+    n_total = [9000 + 173 * i for i in range(len(cfgs))]
+    xs = [synth.mix(n, 40 + i, 9000, 4000, 1 + i % 3) for i, n in enumerate(n_total)]
+    for a, b in ((0.0, 0.37), (0.37, 1.0)):
+        segs = [x[2 * int(a * n): 2 * int(b * n)] for x, n in zip(xs, n_total)]
+        bank.feed(segs)
+        for c, (_, o) in enumerate(pairs):
+            want = o.feed(segs[c])
+            got = bank.read(c)
+            assert got.size == want.size, (c, got.size, want.size)
+            assert ulp_diff(got, want) == 0, c
 
 
 def test_udpsrc_atan2_discriminator_within_tolerance():
@@ -101,9 +125,12 @@ def test_zero_and_constant_input():
     assert ulp_diff(bank.read(0), o.feed(k)) == 0
 
 
-def test_cfg4_pipeline_bank_to_backend_on_device():
+@pytest.mark.parametrize("handover", ["host_sync", "device_ordered"])
+def test_cfg4_pipeline_bank_to_backend_on_device(handover):
     """SURVEY cfg 4 shape at small scale: DownChannelizer bank -> (device hand-over) -> NCO -> Interpolator ->
-    fftfilt SSB -> NFM discriminator, 16 channels, against oracle chain + oracle back-end per channel."""
+    fftfilt SSB -> NFM discriminator, 16 channels, against oracle chain + oracle back-end per channel.
+    device_ordered: sdrx_backend_feed_bank, no host synchronisation between the bank and the back-end, and the bank's
+    queue is dropped and refilled by the next feed straight away (the stream ordering has to protect the samples)."""
     fs = 61_440_000
     n_ch = 16
     k = np.arange(n_ch)
@@ -118,18 +145,32 @@ def test_cfg4_pipeline_bank_to_backend_on_device():
         cfgs.append(g); oras.append(o); chains.append(orc.Chain(modes))
     be = sa.BackendBank(cfgs)
     x = synth.mix(3_000_000, 77, 3000, 1500, 1)
-    for a, b in ((0, 1_000_001), (1_000_001, 3_000_000)):
-        seg = x[2 * a: 2 * b]
-        bank.feed(seg)
-        ptrs, cnts = zip(*[bank.last_dev(c) for c in range(n_ch)])
-        bank.sync()
-        be.feed_dev(ptrs, cnts)
+    cuts = ((0, 1_000_001), (1_000_001, 2_100_000), (2_100_000, 3_000_000))
+    segs = [x[2 * a: 2 * b] for a, b in cuts]
+
+    def check(seg):
         for c in range(n_ch):
             want = oras[c].feed(chains[c].feed(seg))
             got = be.read(c)
             assert got.size == want.size, (c, got.size, want.size)
             assert ulp_diff(got, want) == 0, c
-            bank.skip(c)
+
+    if handover == "host_sync":
+        for seg in segs:
+            bank.feed(seg)
+            ptrs, cnts = zip(*[bank.last_dev(c) for c in range(n_ch)])
+            bank.sync()
+            be.feed_dev(ptrs, cnts)
+            check(seg)
+    else:
+        for i, seg in enumerate(segs):
+            bank.feed(seg)                   # from the second round on this overwrites the queues the back-end was handed
+            if i:
+                check(segs[i - 1])           # ... before the back-end's results for the previous feed are looked at
+            be.feed_bank(bank)
+            for c in range(n_ch):
+                bank.skip(c)
+        check(segs[-1])
 
 
 def test_audio_fir_bank_lowpass_bandpass():
