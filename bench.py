@@ -270,6 +270,13 @@ def main():
                                        "kernel_ms": round(bms, 4), "algorithmic_bytes_per_sample": bps,
                                        "roofline_frac": round(bps * nb / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
             del bank
+        if n_gpus == 1:
+            # the denominator twice -- datasheet (peak/frac above) and a read-only streaming kernel on this box
+            del x
+            torch.cuda.empty_cache()
+            meas = sa.measure_hbm_read(dev.index, 4 << 30, 5)
+            line["roofline"]["peak_measured"] = round(meas, 1)
+            line["roofline"]["frac_of_measured"] = round(achieved / meas, 4)
         if n_gpus == 1 and not args.no_cpu:
             if args.workload == "decim64":
                 line["cpu_baseline"] = cpu_baseline(8 * 1024 * 1024, 16)

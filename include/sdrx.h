@@ -247,6 +247,11 @@ typedef struct sdrx_sdriq_header {
 int sdrx_sdriq_parse_header(const uint8_t* bytes, uint64_t n_bytes, sdrx_sdriq_header* out);
 int sdrx_sdriq_write_header(uint8_t* bytes24, const sdrx_sdriq_header* hdr);
 
+/* ---- diagnostics ----
+ * SURVEY 8(d) quotes the HBM roofline twice: the datasheet's 8 TB/s and what a read-only streaming kernel
+ * (sum of int32 over n_bytes, best of reps launches) reaches on this box.  Not part of the sample path. */
+int sdrx_measure_hbm_read(int device, uint64_t n_bytes, int32_t reps, double* gb_per_s);
+
 #ifdef __cplusplus
 }
 #endif

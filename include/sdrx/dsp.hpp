@@ -21,6 +21,12 @@
 
 namespace sdrx {
 
+// Inside the reference tree the classes below must take the reference's own SampleVector iterators: define
+// SDRX_HOST_SAMPLE to that type (`#define SDRX_HOST_SAMPLE ::Sample` after including dsp/dsptypes.h) and
+// sdrx::Sample becomes an alias of it -- it has to be the packed {int16 re, int16 im} of dsptypes.h:44-65.
+#ifdef SDRX_HOST_SAMPLE
+typedef SDRX_HOST_SAMPLE Sample;
+#else
 #pragma pack(push, 1)
 struct Sample {                                    // dsp/dsptypes.h:44-65
     Sample() : m_real(0), m_imag(0) {}
@@ -32,6 +38,8 @@ struct Sample {                                    // dsp/dsptypes.h:44-65
     int16_t m_real, m_imag;
 };
 #pragma pack(pop)
+#endif
+static_assert(sizeof(Sample) == 4, "Sample must be a packed {int16 re, int16 im}");
 typedef std::vector<Sample> SampleVector;
 
 template<typename StorageType, typename T, unsigned SdrBits, unsigned InputBits>

@@ -1,0 +1,144 @@
+// TEST INFRASTRUCTURE ONLY.  Drop-in check at the reference's own C++ interfaces, in one process:
+//
+//   (1) consumer side: N reference DownChannelizer objects, each feeding a recording
+//       BasebandSampleSink, next to ONE GpuDownChannelizerBank (qt_adapter/) feeding N more recording sinks.
+//       Both sides get the same DSPSignalNotification / channel configuration and the same SampleVector
+//       spans through BasebandSampleSink::feed(); the recorded samples and the MsgChannelizerNotification
+//       (rate, offset) each demod would have received must be identical.  One channel is re-configured
+//       in the middle of the stream.
+//   (2) producer side: the reference's Decimators<qint32,qint16,SDR_RX_SAMP_SZ,12> next to
+//       sdrx::Decimators<...> (include/sdrx/dsp.hpp) with the device thread's call pattern
+//       (limesdrinputthread.cpp:103-135): decimateK_x(&it, buf, len) into a SampleVector, block by block.
+//
+// Built here by `make -C oracle dropin` from the reference sources where they lie (+ moc + Qt5Core of the
+// image) into oracle/_ref/dropin_test; run on the GPU box by tests/test_dropin_gpu.py.  Prints one line per
+// check and exits non-zero on any mismatch.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "dsp/downchannelizer.h"
+#include "dsp/dspcommands.h"
+#include "dsp/decimators.h"
+#include "util/messagequeue.h"
+#include "gpudownchannelizerbank.h"
+#define SDRX_HOST_SAMPLE ::Sample      // sdrx::Decimators then takes the reference's SampleVector::iterator*
+#include "sdrx/dsp.hpp"
+#include "dropin_common.hpp"
+
+uint32_t dropin_rng_state = 12345u;
+int dropin_fails = 0;
+void producer_side_u(int device);      // dropin_test_u.cpp
+
+namespace {
+
+class RecorderSink : public BasebandSampleSink {
+public:
+    std::vector<Sample> got;
+    std::vector<int> notes;            // (rate, offset) pairs of MsgChannelizerNotification, in arrival order
+    int feeds;
+    RecorderSink() : feeds(0) {}
+    void start() override {}
+    void stop() override {}
+    void feed(const SampleVector::const_iterator& b, const SampleVector::const_iterator& e, bool) override
+    { got.insert(got.end(), b, e); feeds++; }
+    // BasebandSampleSink::handleInputMessages (basebandsamplesink.cpp:19-25) runs on messageEnqueued -- a direct call here,
+    // the demod's own thread in the application -- and deletes what handleMessage() accepts
+    bool handleMessage(const Message& m) override
+    {
+        if (DownChannelizer::MsgChannelizerNotification::match(m)) {
+            const DownChannelizer::MsgChannelizerNotification& n = (const DownChannelizer::MsgChannelizerNotification&) m;
+            notes.push_back(n.getSampleRate()); notes.push_back(n.getFrequencyOffset());
+        }
+        return true;
+    }
+    void pump() { Message* m; while ((m = getInputMessageQueue()->pop()) != 0) { handleMessage(*m); delete m; } }
+};
+
+void consumer_side(int device)
+{
+    const int fs = 61440000, N = 12;
+    std::vector<RecorderSink*> refSinks, gpuSinks;
+    std::vector<DownChannelizer*> refs;
+    GpuDownChannelizerBank bank(device);
+    DSPSignalNotification sig(fs, 0);
+    for (int c = 0; c < N; c++) {
+        refSinks.push_back(new RecorderSink); gpuSinks.push_back(new RecorderSink);
+        refs.push_back(new DownChannelizer(refSinks[c]));
+        bank.addChannel(gpuSinks[c]);
+    }
+    for (int c = 0; c < N; c++) refs[c]->handleMessage(sig);
+    bank.handleMessage(sig);
+    std::vector<int> rate(N), fc(N);
+    for (int c = 0; c < N; c++) {
+        rate[c] = (c % 3 == 2) ? 96000 : (c % 4 == 1) ? 12000 : 48000;
+        fc[c] = -15000000 + (int)(c * (30000000.0 / 11)) + 137 * c;      // mixes lower/upper/centre paths and depths 8..12
+        DSPConfigureChannelizer cfg(rate[c], fc[c]);
+        refs[c]->handleMessage(cfg);
+        bank.configureChannel(c, rate[c], fc[c]);
+    }
+    // spans of uneven length, as the engine's work() hands them over (two parts of the FIFO ring)
+    const int spans[] = { 32768, 1, 65535, 100000, 3, 262144, 77777 };
+    long total = 0;
+    for (size_t s = 0; s < sizeof spans / sizeof spans[0]; s++) {
+        SampleVector v((size_t) spans[s]);
+        for (int i = 0; i < spans[s]; i++) v[i] = Sample((qint16)((int)(rng() % 4096) - 2048), (qint16)((int)(rng() % 4096) - 2048));
+        if (s == 4) {                  // DSPConfigureChannelizer for one channel while the others keep running
+            rate[5] = 24000; fc[5] = 1234567;
+            DSPConfigureChannelizer cfg(rate[5], fc[5]);
+            refs[5]->handleMessage(cfg);
+            bank.configureChannel(5, rate[5], fc[5]);
+        }
+        for (int c = 0; c < N; c++) refs[c]->feed(v.begin(), v.end(), false);
+        bank.feed(v.begin(), v.end(), false);
+        total += spans[s];
+    }
+    for (int c = 0; c < N; c++) {
+        refSinks[c]->pump(); gpuSinks[c]->pump();
+        char what[96];
+        const std::vector<Sample>& a = refSinks[c]->got; const std::vector<Sample>& b = gpuSinks[c]->got;
+        bool same = a.size() == b.size();
+        for (size_t i = 0; same && i < a.size(); i++) same = a[i].real() == b[i].real() && a[i].imag() == b[i].imag();
+        snprintf(what, sizeof what, "channel %2d samples DownChannelizer vs GPU bank", c);
+        report(what, same && !a.empty(), (long) a.size());
+        // the last notification is the configuration in force; the reference posts one per applyConfiguration
+        const std::vector<int>& na = refSinks[c]->notes; const std::vector<int>& nb = gpuSinks[c]->notes;
+        const bool notes_ok = na.size() >= 2 && nb.size() >= 2 && na[na.size() - 2] == nb[nb.size() - 2] && na[na.size() - 1] == nb[nb.size() - 1];
+        snprintf(what, sizeof what, "channel %2d MsgChannelizerNotification (rate %d, ofs %d)", c, na.size() >= 2 ? na[na.size() - 2] : -1, na.size() >= 2 ? na[na.size() - 1] : -1);
+        report(what, notes_ok, (long) nb.size() / 2);
+        if (!notes_ok) {
+            printf("    reference:"); for (size_t i = 0; i < na.size(); i++) printf(" %d", na[i]);
+            printf("\n    gpu bank: "); for (size_t i = 0; i < nb.size(); i++) printf(" %d", nb[i]);
+            printf("\n");
+        }
+    }
+    printf("consumer side: %ld input samples through %d channels\n", total, N);
+    for (int c = 0; c < N; c++) { delete refs[c]; refSinks[c]->pump(); gpuSinks[c]->pump(); }
+}
+
+void producer_side(int device)
+{
+    typedef Decimators<qint32, qint16, SDR_RX_SAMP_SZ, 12> RefDec12;
+    typedef sdrx::Decimators<qint32, qint16, SDR_RX_SAMP_SZ, 12> GpuDec12;
+    typedef Decimators<qint32, qint16, SDR_RX_SAMP_SZ, 16> RefDec16;
+    typedef sdrx::Decimators<qint32, qint16, SDR_RX_SAMP_SZ, 16> GpuDec16;
+    PRODUCER(RefDec12, GpuDec12, qint16, decimate64_cen, -2048, 4096)      // LimeSDR / sdrbench configuration
+    PRODUCER(RefDec12, GpuDec12, qint16, decimate16_cen, -2048, 4096)
+    PRODUCER(RefDec12, GpuDec12, qint16, decimate8_inf, -2048, 4096)
+    PRODUCER(RefDec12, GpuDec12, qint16, decimate32_sup, -2048, 4096)
+    PRODUCER(RefDec12, GpuDec12, qint16, decimate2_cen, -2048, 4096)
+    PRODUCER(RefDec12, GpuDec12, qint16, decimate1, -2048, 4096)
+    PRODUCER(RefDec16, GpuDec16, qint16, decimate4_inf, -32768, 65536)      // full-scale 16-bit source
+}
+
+} // namespace
+
+int main(int argc, char** argv)
+{
+    const int device = argc > 1 ? atoi(argv[1]) : 0;
+    consumer_side(device);
+    producer_side(device);
+    producer_side_u(device);
+    printf(dropin_fails ? "DROP-IN CHECK FAILED: %d mismatches\n" : "DROP-IN CHECK PASSED%.0d\n", dropin_fails);
+    return dropin_fails ? 1 : 0;
+}

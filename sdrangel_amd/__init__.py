@@ -97,6 +97,7 @@ def lib() -> C.CDLL:
         "sdrx_backend_feed": (C.c_int, [vp, vp, vp]),
         "sdrx_backend_feed_dev": (C.c_int, [vp, vp, vp]),
         "sdrx_backend_feed_bank": (C.c_int, [vp, vp]),
+        "sdrx_measure_hbm_read": (C.c_int, [C.c_int, C.c_uint64, C.c_int32, C.POINTER(C.c_double)]),
         "sdrx_backend_read": (i64, [vp, i32, vp, i64]),
         "sdrx_backend_get_design": (C.c_int, [vp, i32, C.POINTER(i32), vp, i32, vp, C.POINTER(i32)]),
         "sdrx_backend_sync": (C.c_int, [vp]),
@@ -480,3 +481,10 @@ class SampleSinkFifo:
 
     def read_commit(self, count: int) -> int:
         return lib().sdrx_fifo_read_commit(self._h, count)
+
+
+def measure_hbm_read(device: int = 0, n_bytes: int = 4 << 30, reps: int = 5) -> float:
+    """GB/s of a read-only streaming kernel over n_bytes of HBM (best of reps) -- the measured roofline denominator"""
+    v = C.c_double()
+    _check(lib().sdrx_measure_hbm_read(device, n_bytes, reps, C.byref(v)), "sdrx_measure_hbm_read")
+    return v.value

@@ -137,6 +137,60 @@ int sdrx_sdriq_write_header(uint8_t* bytes24, const sdrx_sdriq_header* hdr)
     return SDRX_OK;
 }
 
+/* ------------------------------------------------------------------ measured HBM read ceiling
+ * the roofline denominator is quoted twice -- the 8 TB/s datasheet figure and what a read-only
+ * streaming kernel (sum of int32) reaches on this very box.  Diagnostic only; not on the sample path.    */
+namespace {
+__global__ void __launch_bounds__(256) sdrx_stream_sum_kernel(const uint4* __restrict__ p, size_t n_vec, uint32_t* __restrict__ sink)
+{
+    uint32_t acc = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n_vec; i += 4 * stride) {       // four independent 16-byte loads in flight per lane
+        const uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+        acc += a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w + c.x + c.y + c.z + c.w + d.x + d.y + d.z + d.w;
+    }
+    for (; i < n_vec; i += stride) { const uint4 a = p[i]; acc += a.x + a.y + a.z + a.w; }
+    if (acc == 0x9e3779b9u) atomicAdd(sink, acc);            // keeps the loads alive, practically never taken
+}
+}
+
+int sdrx_measure_hbm_read(int device, uint64_t n_bytes, int32_t reps, double* gb_per_s)
+{
+    if (!gb_per_s || n_bytes < (1u << 20) || reps < 1) { sdrx::set_error("sdrx_measure_hbm_read: bad argument"); return SDRX_EINVAL; }
+    int rc = sdrx::check_device(device); if (rc) return rc;
+    SDRX_HIP(hipSetDevice(device));
+    void* buf = nullptr; uint32_t* sink = nullptr;
+    SDRX_HIP(hipMalloc(&buf, n_bytes));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&sink), 4);
+    if (e != hipSuccess) { (void)hipFree(buf); return sdrx::hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    double best_ms = 1e30;
+    e = hipMemset(buf, 1, n_bytes);
+    if (e == hipSuccess) e = hipMemset(sink, 0, 4);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    const size_t n_vec = n_bytes / 16;
+    for (unsigned blocks_per_cu : { 4u, 8u, 16u, 32u }) {     // the best grid shape counts: this is a ceiling, not a product kernel
+        for (int r = 0; r < reps + 1 && e == hipSuccess; r++) {  // first launch of a shape is a warm-up
+            e = hipEventRecord(e0, nullptr);
+            hipLaunchKernelGGL(sdrx_stream_sum_kernel, dim3(256 * blocks_per_cu), dim3(256), 0, nullptr, static_cast<const uint4*>(buf), n_vec, sink);
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e == hipSuccess && r > 0 && ms < best_ms) best_ms = ms;
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(buf); (void)hipFree(sink);
+    if (e != hipSuccess) return sdrx::hip_fail(e, "sdrx_measure_hbm_read", __FILE__, __LINE__);
+    *gb_per_s = (double)(n_vec * 16) / (best_ms * 1e-3) / 1e9;
+    return SDRX_OK;
+}
+
 /* ------------------------------------------------------------------ SampleSinkFifo mirror
  * Same observable contract as sdrbase/dsp/samplesinkfifo.cpp:70-231: a writer may add at most
  * size-fill samples (the rest is dropped and counted), readers see up to two contiguous spans,

@@ -1,0 +1,29 @@
+"""Drop-in check at the reference's own C++ interfaces, on the GPU: oracle/_ref/dropin_test holds the
+reference's DownChannelizer and Decimators/DecimatorsU classes (compiled from /root/reference in the build container,
+where `make -C oracle dropin` / __graft_entry__.build() produce it) next to qt_adapter/GpuDownChannelizerBank and the
+sdrx::Decimators mirror of include/sdrx/dsp.hpp, feeds both sides the same SampleVector spans / device-thread blocks
+through BasebandSampleSink::feed() and decimateK_x(&it, buf, len), and compares every output sample and the
+MsgChannelizerNotification each demod receives.  The binary needs Qt5Core of the image (/opt/conda/lib)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "oracle", "_ref", "dropin_test")
+QT = "/opt/conda/lib/libQt5Core.so.5"
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.skipif(not (os.path.exists(EXE) and os.path.exists(QT)), reason="drop-in harness not built (needs /root/reference + Qt at build time)")
+def test_reference_objects_and_gpu_adapter_agree_in_one_process():
+    env = dict(os.environ)
+    sys_stdcpp = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"      # conda's lib dir (rpath for Qt) carries an older libstdc++
+    if os.path.exists(sys_stdcpp):
+        env["LD_PRELOAD"] = sys_stdcpp
+    out = subprocess.run([EXE, "0"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, (out.returncode, out.stdout[-3000:], out.stderr[-2000:])
+    assert "DROP-IN CHECK PASSED" in out.stdout
+    assert out.stdout.count(" OK ") >= 12 * 2 + 12, out.stdout
+    assert "MISMATCH" not in out.stdout
