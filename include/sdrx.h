@@ -247,6 +247,35 @@ typedef struct sdrx_sdriq_header {
 int sdrx_sdriq_parse_header(const uint8_t* bytes, uint64_t n_bytes, sdrx_sdriq_header* out);
 int sdrx_sdriq_write_header(uint8_t* bytes24, const sdrx_sdriq_header* hdr);
 
+/* ---- float half-band decimators ----
+ * DecimatorsFI (sdrbase/dsp/decimatorsfi.h:29-57: float I/Q in, int16 Sample out; the AirspyHF thread's member,
+ * plugins/samplesource/airspyhf/airspyhfthread.h), DecimatorsFF (decimatorsff.h: float in, float FSample out) and
+ * DecimatorsIF<qint16,InputBits> (decimatorsif.h:52-79: int16 in, float out), all over IntHalfbandFilterEOF<64>
+ * (inthalfbandfiltereof.h).  One handle = one decimateK_{inf,sup,cen} method of one object: (log2_decim, fcpos).
+ *   in_kind  0 float I/Q            1 int16 I/Q, scaled by decimation_scale<input_bits> (8|12|16) at the output
+ *   out_kind 0 int16 Sample = (int16)(v * SDR_RX_SCALED), truncation (float input only)      1 float re, im
+ * n_elems = the reference's nbIAndQ (floats or int16s); whole groups only, tail dropped; filter state carried.
+ * Results are bit-identical to the reference built without -ffast-math (same operation order, no FMA). */
+typedef struct sdrx_fdecim sdrx_fdecim_t;
+#define SDRX_FD_IN_F32  0
+#define SDRX_FD_IN_I16  1
+#define SDRX_FD_OUT_I16 0
+#define SDRX_FD_OUT_F32 1
+int sdrx_fdecim_create(sdrx_fdecim_t** out, int device, int log2_decim, int fcpos, int in_kind, int out_kind, int input_bits);
+int sdrx_fdecim_destroy(sdrx_fdecim_t* h);
+int sdrx_fdecim_reset(sdrx_fdecim_t* h);
+/* host pointers; blocking.  *n_out_cplx = advance of the reference's output iterator */
+int sdrx_fdecim_process(sdrx_fdecim_t* h, const void* in, int32_t n_elems, void* out, int32_t* n_out_cplx);
+/* device pointers (d_in 16-byte, d_out 8-byte aligned); asynchronous on the handle's stream */
+int sdrx_fdecim_process_dev(sdrx_fdecim_t* h, const void* d_in, int64_t n_elems, void* d_out, int64_t* n_out_cplx);
+int sdrx_fdecim_sync(sdrx_fdecim_t* h);
+int sdrx_fdecim_set_stream(sdrx_fdecim_t* h, void* hip_stream);
+/* input elements per loop iteration of the reference method (its `pos +=` stride) */
+int32_t sdrx_fdecim_group(int log2_decim, int fcpos);
+int sdrx_fdecim_set_timing(sdrx_fdecim_t* h, int enabled);
+int sdrx_fdecim_get_timing(sdrx_fdecim_t* h, double* total_ms, int64_t* launches, int reset);
+int sdrx_fdecim_last_launch(const sdrx_fdecim_t* h, char* kernel_name, int name_cap, int* grid, int* block, int* lds_bytes);
+
 /* ---- diagnostics ----
  * SURVEY 8(d) quotes the HBM roofline twice: the datasheet's 8 TB/s and what a read-only streaming kernel
  * (sum of int32 over n_bytes, best of reps launches) reaches on this box.  Not part of the sample path. */

@@ -81,6 +81,16 @@ void    sdro_fir_free(sdro_fir*);
 int32_t sdro_fir_taps(const sdro_fir*, float* out);                      /* ntaps/2 + 1 folded taps */
 void    sdro_fir_run(sdro_fir*, const float* in, int64_t n, float* out); /* streaming: state carried */
 
+/* ---- float half-band decimators: DecimatorsFI / FF / IF over IntHalfbandFilterEOF<64> (oracle/sdro_fdecim.c) ----
+ * in_kind 0: float I/Q, 1: int16 I/Q (DecimatorsIF<qint16,input_bits>); out_kind 0: int16 Sample (FI), 1: float (FF, IF).
+ * n_elems = the reference's nbIAndQ; returns #complex outputs (whole groups only, tail dropped). */
+typedef struct sdro_fdecim sdro_fdecim;
+sdro_fdecim* sdro_fdecim_new(int log2_decim, int fcpos, int in_kind, int out_kind, int input_bits);
+void    sdro_fdecim_free(sdro_fdecim*);
+void    sdro_fdecim_reset(sdro_fdecim*);
+int32_t sdro_fdecim_process(sdro_fdecim*, const void* in, int32_t n_elems, void* out);
+int32_t sdro_fdecim_group(int log2_decim, int fcpos);      /* elements per loop iteration of the reference function */
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,6 +98,17 @@ def lib() -> C.CDLL:
         "sdrx_backend_feed_dev": (C.c_int, [vp, vp, vp]),
         "sdrx_backend_feed_bank": (C.c_int, [vp, vp]),
         "sdrx_measure_hbm_read": (C.c_int, [C.c_int, C.c_uint64, C.c_int32, C.POINTER(C.c_double)]),
+        "sdrx_fdecim_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "sdrx_fdecim_destroy": (C.c_int, [vp]),
+        "sdrx_fdecim_reset": (C.c_int, [vp]),
+        "sdrx_fdecim_process": (C.c_int, [vp, vp, C.c_int32, vp, C.POINTER(C.c_int32)]),
+        "sdrx_fdecim_process_dev": (C.c_int, [vp, vp, C.c_int64, vp, C.POINTER(C.c_int64)]),
+        "sdrx_fdecim_sync": (C.c_int, [vp]),
+        "sdrx_fdecim_set_stream": (C.c_int, [vp, vp]),
+        "sdrx_fdecim_group": (C.c_int32, [C.c_int, C.c_int]),
+        "sdrx_fdecim_set_timing": (C.c_int, [vp, C.c_int]),
+        "sdrx_fdecim_get_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
+        "sdrx_fdecim_last_launch": (C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "sdrx_backend_read": (i64, [vp, i32, vp, i64]),
         "sdrx_backend_get_design": (C.c_int, [vp, i32, C.POINTER(i32), vp, i32, vp, C.POINTER(i32)]),
         "sdrx_backend_sync": (C.c_int, [vp]),
@@ -230,6 +241,62 @@ class DecimatorsU(Decimators):
         n = C.c_int32()
         _check(lib().sdrx_decim_process_u8(self._h, buf.ctypes.data, buf.size, out.ctypes.data, C.byref(n)), "sdrx_decim_process_u8")
         return out[: 2 * n.value]
+
+
+class FloatDecimators:
+    """The float half-band decimators over IntHalfbandFilterEOF<64>, one (log2, fcpos) per object:
+    kind "fi" = DecimatorsFI (float I/Q -> int16 Sample; AirspyHF), "ff" = DecimatorsFF (float -> float),
+    "if" = DecimatorsIF<qint16, input_bits> (int16 -> float).  `decimate(buf)` == decimateK_{inf,sup,cen}(&it, buf, nbIAndQ)."""
+
+    KINDS = {"fi": (0, 0), "ff": (0, 1), "if": (1, 1)}
+
+    def __init__(self, kind: str, log2_decim: int, fcpos: int = FC_CEN, input_bits: int = 16, device: int = 0):
+        self.in_kind, self.out_kind = self.KINDS[kind]
+        self._h = C.c_void_p()
+        _check(lib().sdrx_fdecim_create(C.byref(self._h), device, log2_decim, fcpos, self.in_kind, self.out_kind, input_bits), "sdrx_fdecim_create")
+        self.kind, self.log2, self.fcpos = kind, log2_decim, fcpos
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sdrx_fdecim_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def reset(self):
+        _check(lib().sdrx_fdecim_reset(self._h), "sdrx_fdecim_reset")
+
+    def decimate(self, buf) -> np.ndarray:
+        buf = np.ascontiguousarray(buf, dtype=np.float32 if self.in_kind == 0 else np.int16)
+        out = np.empty(buf.size + 8, np.int16 if self.out_kind == 0 else np.float32)
+        n = C.c_int32()
+        _check(lib().sdrx_fdecim_process(self._h, buf.ctypes.data, buf.size, out.ctypes.data, C.byref(n)), "sdrx_fdecim_process")
+        return out[: 2 * n.value]
+
+    def decimate_dev(self, d_in_ptr: int, n_elems: int, d_out_ptr: int) -> int:
+        n = C.c_int64()
+        _check(lib().sdrx_fdecim_process_dev(self._h, d_in_ptr, n_elems, d_out_ptr, C.byref(n)), "sdrx_fdecim_process_dev")
+        return n.value
+
+    def sync(self):
+        _check(lib().sdrx_fdecim_sync(self._h), "sdrx_fdecim_sync")
+
+    def set_stream(self, hip_stream: int | None):
+        _check(lib().sdrx_fdecim_set_stream(self._h, hip_stream), "sdrx_fdecim_set_stream")
+
+    def set_timing(self, on: bool):
+        _check(lib().sdrx_fdecim_set_timing(self._h, int(on)), "sdrx_fdecim_set_timing")
+
+    def get_timing(self, reset: bool = True):
+        ms, n = C.c_double(), C.c_int64()
+        _check(lib().sdrx_fdecim_get_timing(self._h, C.byref(ms), C.byref(n), int(reset)), "sdrx_fdecim_get_timing")
+        return ms.value, n.value
+
+    def last_launch(self) -> dict:
+        name = C.create_string_buffer(128)
+        g, b, l = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().sdrx_fdecim_last_launch(self._h, name, 128, C.byref(g), C.byref(b), C.byref(l)), "last_launch")
+        return {"kernel": name.value.decode(), "grid": g.value, "block": b.value, "lds_bytes": l.value}
 
 
 def chan_plan(in_rate: int, req_rate: int, req_fc: int):

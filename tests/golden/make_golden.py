@@ -197,6 +197,26 @@ def main():
         ref.ref_fir_run(h, d.ctypes.data, d.size, o.ctypes.data)
         fl[nm] = o
     np.savez_compressed(os.path.join(HERE, "float_golden.npz"), **fl)
+
+    # ---- float half-band decimators: DecimatorsFI / FF / IF<qint16,12> (oracle/ref_shim_f.cpp)
+    ref.ref_fdecim_new.restype = vp; ref.ref_fdecim_new.argtypes = [C.c_int] * 3
+    ref.ref_fdecim_free.argtypes = [vp]
+    ref.ref_fdecim_process.restype = C.c_int; ref.ref_fdecim_process.argtypes = [vp, C.c_int, C.c_int, vp, i32, vp]
+    fd = {}
+    for kind, (ik, ok, bits) in {"fi": (0, 0, 16), "ff": (0, 1, 16), "if12": (1, 1, 12)}.items():
+        for L, fc in synth.FDECIM_CASES:
+            n = 3000 if L <= 2 else 24000
+            x = synth.fdecim_input(kind, n, 100 + 7 * L + fc)
+            h = ref.ref_fdecim_new(ik, ok, bits)
+            outs = []
+            for a, b in synth.fdecim_cuts(n):
+                seg = np.ascontiguousarray(x[2 * a: 2 * b])
+                o = np.zeros(seg.size + 8, np.int16 if ok == 0 else np.float32)
+                k = ref.ref_fdecim_process(h, L, fc, seg.ctypes.data, seg.size, o.ctypes.data)
+                outs.append(o[: 2 * k].copy())
+            ref.ref_fdecim_free(h)
+            fd[f"{kind}_L{L}_fc{fc}"] = np.concatenate(outs)
+    np.savez_compressed(os.path.join(HERE, "fdecim_golden.npz"), **fd)
     print("golden written:", sorted(os.listdir(HERE)))
 
 

@@ -36,6 +36,35 @@ def _sig(L):
     L.sdro_chain_feed.restype = i64; L.sdro_chain_feed.argtypes = [vp, vp, i64, vp]
 
 
+def _sig_fdecim(L):
+    vp, i32 = C.c_void_p, C.c_int32
+    L.sdro_fdecim_new.restype = vp; L.sdro_fdecim_new.argtypes = [C.c_int] * 5
+    L.sdro_fdecim_free.argtypes = [vp]; L.sdro_fdecim_reset.argtypes = [vp]
+    L.sdro_fdecim_process.restype = i32; L.sdro_fdecim_process.argtypes = [vp, vp, i32, vp]
+    L.sdro_fdecim_group.restype = i32; L.sdro_fdecim_group.argtypes = [C.c_int] * 2
+
+
+class FDecim:
+    """oracle DecimatorsFI ("fi") / DecimatorsFF ("ff") / DecimatorsIF<qint16,bits> ("if"), one (log2, fcpos)"""
+    KINDS = {"fi": (0, 0), "ff": (0, 1), "if": (1, 1)}
+
+    def __init__(self, kind, log2, fcpos, bits=16):
+        self.L = lib(); _sig_fdecim(self.L)
+        self.ik, self.ok = self.KINDS[kind]
+        self.h = self.L.sdro_fdecim_new(log2, fcpos, self.ik, self.ok, bits)
+        assert self.h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.sdro_fdecim_free(self.h); self.h = None
+
+    def process(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.float32 if self.ik == 0 else np.int16)
+        out = np.zeros(buf.size + 8, np.int16 if self.ok == 0 else np.float32)
+        n = self.L.sdro_fdecim_process(self.h, buf.ctypes.data, buf.size, out.ctypes.data)
+        return out[: 2 * n]
+
+
 def _sig_float(L):
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     L.sdro_nco_table.argtypes = [vp]

@@ -64,3 +64,20 @@ def fnv1a64(a: np.ndarray) -> int:
     for b in np.ascontiguousarray(a).view(np.uint8).tobytes():
         h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
     return h
+
+
+# float half-band decimator fixtures (tests/golden/fdecim_golden.npz): inputs are integer-generated and scaled by an
+# exact power of two, so every platform rebuilds the same float32 bits
+FDECIM_CASES = [(0, 2), (1, 0), (1, 1), (1, 2), (2, 0), (2, 1), (2, 2), (3, 0), (3, 1), (3, 2), (4, 1), (4, 2), (5, 0), (6, 0), (6, 1), (6, 2)]
+
+
+def fdecim_input(kind, n_cplx, seed):
+    x = mix(n_cplx, seed, 2000, 900, 1)                    # int16 I/Q, |x| < 2048
+    if kind.startswith("if"):
+        return x
+    return (x.astype(np.float32) / np.float32(4096.0)).astype(np.float32)      # |x| < 0.5, exact
+
+
+def fdecim_cuts(n_cplx):
+    c = [0, 1000, 1001, n_cplx // 2 + 3, n_cplx]
+    return list(zip(c[:-1], c[1:]))

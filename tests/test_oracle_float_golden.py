@@ -65,3 +65,16 @@ def test_gfft_agrees_with_numpy_fft_numerically():
         assert np.max(np.abs(got - want)) < 1e-3 * np.sqrt(n)
         b = a.copy(); L.sdro_gfft(b.ctypes.data, n, 1)
         assert np.max(np.abs(b - x)) < 1e-4
+
+
+def test_float_decimators_oracle_vs_reference_vectors():
+    """DecimatorsFI / FF / IF<qint16,12>: oracle/sdro_fdecim.c against outputs of the compiled reference classes"""
+    g = np.load(os.path.join(G, "fdecim_golden.npz"))
+    for kind, okind, nbits in (("fi", "fi", 16), ("ff", "ff", 16), ("if12", "if", 12)):
+        for L, fc in synth.FDECIM_CASES:
+            n = 3000 if L <= 2 else 24000
+            x = synth.fdecim_input(kind, n, 100 + 7 * L + fc)
+            o = orc.FDecim(okind, L, fc, nbits)
+            y = np.concatenate([o.process(x[2 * a: 2 * b]) for a, b in synth.fdecim_cuts(n)])
+            want = g[f"{kind}_L{L}_fc{fc}"]
+            assert y.size == want.size and np.array_equal(y.view(np.uint8), want.view(np.uint8)), (kind, L, fc)

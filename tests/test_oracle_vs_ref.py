@@ -134,3 +134,27 @@ def test_audio_firs_vs_reference():
             x = rng.standard_normal(n).astype(np.float32); A = np.zeros(n + 1, np.float32)
             L.ref_fir_run(hr, x.ctypes.data, n, A.ctypes.data)
             assert np.array_equal(A[:n].view(np.uint32), o.run(x).view(np.uint32)), (kind, nt, n)
+
+
+def test_float_decimators_fi_ff_if_random_blocks():
+    """oracle/sdro_fdecim.c vs the reference's DecimatorsFI / DecimatorsFF / DecimatorsIF<qint16,{8,12,16}> objects:
+    every K and fcPos, state carried over ragged blocks, bit-identical (float outputs compared as raw bits)"""
+    L_ = C.CDLL(REF)
+    vp = C.c_void_p
+    L_.ref_fdecim_new.restype = vp; L_.ref_fdecim_new.argtypes = [C.c_int] * 3
+    L_.ref_fdecim_free.argtypes = [vp]
+    L_.ref_fdecim_process.restype = C.c_int; L_.ref_fdecim_process.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int32, vp]
+    rng = np.random.default_rng(5)
+    for kind, ik, ok, bits in (("fi", 0, 0, 16), ("ff", 0, 1, 16), ("if", 1, 1, 8), ("if", 1, 1, 12), ("if", 1, 1, 16)):
+        for log2 in range(7):
+            for fc in range(3):
+                if log2 == 0 and fc != 2:
+                    continue
+                o = orc.FDecim(kind, log2, fc, bits); h = L_.ref_fdecim_new(ik, ok, bits)
+                for blk in (2 * 4096 + 6, 2, 130, 40000, 0, 2 * 777):
+                    x = rng.uniform(-0.95, 0.95, blk).astype(np.float32) if ik == 0 else rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), blk).astype(np.int16)
+                    want = np.zeros(blk + 16, np.int16 if ok == 0 else np.float32)
+                    n = L_.ref_fdecim_process(h, log2, fc, x.ctypes.data, blk, want.ctypes.data)
+                    got = o.process(x)
+                    assert got.size == 2 * n and np.array_equal(got.view(np.uint8), want[: 2 * n].view(np.uint8)), (kind, bits, log2, fc, blk)
+                L_.ref_fdecim_free(h)
