@@ -86,6 +86,49 @@ def cpu_baseline(sample_cplx: int, reps: int, log2: int = 6):
                       f"one independent stream per thread ({n_thr} threads); single_thread_MSps = 1 thread, as sdrangelbench runs it"}
 
 
+def cpu_baseline_fi(sample_cplx: int, reps: int):
+    """Reference (or port) DecimatorsFI::decimate64_cen, one stream per thread, on the host cores."""
+    import numpy as np
+    from tests import oracle_py as orc
+    n_thr = max(1, min(os.cpu_count() or 1, 16))
+    x = (orc.synth_iq(sample_cplx, seed=99, amp=2047).astype(np.float32) / np.float32(4096.0))
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libsdrref.so")
+    kind = "port"
+    L = None
+    if os.path.exists(ref_so):
+        try:
+            L = C.CDLL(ref_so)
+            L.ref_fdecim_new.restype = C.c_void_p; L.ref_fdecim_new.argtypes = [C.c_int] * 3
+            L.ref_fdecim_process.restype = C.c_int; L.ref_fdecim_process.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int32, C.c_void_p]
+            kind = "reference"
+        except (OSError, AttributeError):
+            L = None
+    if L is not None:
+        mk = lambda: L.ref_fdecim_new(0, 0, 16)
+        run = lambda h, out: L.ref_fdecim_process(h, 6, 2, x.ctypes.data, x.size, out.ctypes.data)
+    else:
+        O = orc.lib(); orc._sig_fdecim(O)
+        mk = lambda: O.sdro_fdecim_new(6, 2, 0, 0, 16)
+        run = lambda h, out: O.sdro_fdecim_process(h, x.ctypes.data, x.size, out.ctypes.data)
+
+    def timed(n_threads):
+        hs = [mk() for _ in range(n_threads)]
+        outs = [np.empty(x.size + 64, np.int16) for _ in range(n_threads)]
+        def work(i):
+            for _ in range(reps):
+                run(hs[i], outs[i])
+        th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+        t0 = time.perf_counter()
+        for t in th: t.start()
+        for t in th: t.join()
+        return n_threads * reps * sample_cplx / (time.perf_counter() - t0) / 1e6
+
+    one = timed(1)
+    allc = timed(n_thr) if n_thr > 1 else one
+    return {"value": round(allc, 2), "unit": "MS/s", "cores": n_thr, "kind": kind, "single_thread_MSps": round(one, 2),
+            "sample": f"DecimatorsFI::decimate64_cen on {sample_cplx} synthetic float I/Q samples x {reps} passes per thread, one stream per thread ({n_thr} threads)"}
+
+
 def cpu_baseline_chan(fcs, sample_cplx: int):
     """Reference DownChannelizer stage chains (IntHalfbandFilterEO<qint32,qint32,48> objects driven by the loop of
     DownChannelizer::feed), every channel re-filtering the full-rate stream on its own thread like
@@ -148,7 +191,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="decim64", choices=["decim64", "chan32", "chan128", "cfg4"])
+    ap.add_argument("--workload", default="decim64", choices=["decim64", "chan32", "chan128", "cfg4", "fi64"])
     ap.add_argument("--batch", type=int, default=256 * 1024 * 1024, help="complex samples per step per GPU (1 GiB of int16 I/Q)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary cfg-3 (32-channel bank) measurement")
@@ -178,7 +221,19 @@ def main():
     del t
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    if args.workload == "decim64":
+    if args.workload == "fi64":
+        # DecimatorsFI::decimate64_cen (AirspyHF thread), float I/Q in, int16 Samples out
+        B = min(B, 128 * 1024 * 1024)
+        xf = (x[: 2 * B].to(torch.float32) / 4096.0).contiguous()
+        del x
+        x = xf
+        h = sa.FloatDecimators("fi", 6, sa.FC_CEN, device=dev.index)
+        out = torch.empty(2 * (B >> 6) + 64, dtype=torch.int16, device=dev)
+        h.set_stream(stream)
+        step = lambda: h.decimate_dev(x.data_ptr(), 2 * B, out.data_ptr())
+        bytes_per_sample = 8.0 + 4.0 / 64
+        workload = f"8f.4: DecimatorsFI::decimate64_cen (IntHalfbandFilterEOF<64> x 6), one stream per GPU, {B} complex float32 samples per step, device-resident"
+    elif args.workload == "decim64":
         h = sa.Decimators(6, sa.FC_CEN, 12, device=dev.index)
         out = torch.empty(2 * (B >> 6) + 64, dtype=torch.int16, device=dev)
         h.set_stream(stream)
@@ -233,7 +288,7 @@ def main():
             "metric": "MS/s complex int16 IQ through decim-64 + DownChannelizer, 1/2/4/8 GPU; % HBM roofline",
             "value": round(value, 1), "unit": "MS/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.workload == "fi64" else "int32", "data": "synthetic",
             "config": {"workload": workload, "streams": n_gpus, "parallelism": f"{n_gpus} independent stream(s), one per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -278,7 +333,9 @@ def main():
             line["roofline"]["peak_measured"] = round(meas, 1)
             line["roofline"]["frac_of_measured"] = round(achieved / meas, 4)
         if n_gpus == 1 and not args.no_cpu:
-            if args.workload == "decim64":
+            if args.workload == "fi64":
+                line["cpu_baseline"] = cpu_baseline_fi(4 * 1024 * 1024, 8)
+            elif args.workload == "decim64":
                 line["cpu_baseline"] = cpu_baseline(8 * 1024 * 1024, 16)
             else:
                 line["cpu_baseline"] = cpu_baseline_chan(fcs, 4 * 1024 * 1024)

@@ -7,6 +7,7 @@
 //   Decimators<qint32,qint16,16,B> (dsp/decimators.h:279)  sdrx::Decimators<int32_t,int16_t,16,B>
 //   DownChannelizer               (dsp/downchannelizer.h)  sdrx::DownChannelizerBank (N channels, one stream)
 //   SampleSinkFifo                (dsp/samplesinkfifo.h)   sdrx::SampleSinkFifo
+//   DecimatorsFI / FF / IF<T,B>   (dsp/decimatorsf*.h, decimatorsif.h)  sdrx::DecimatorsFI / DecimatorsFF / DecimatorsIF<T,B>
 //
 // Differences that are visible: (1) the reference keeps ONE set of six stage states per Decimators
 // object shared by all decimateK_* methods; here every (K, fcPos) pair owns its state (handle created
@@ -112,6 +113,68 @@ private:
     }
     int m_device;
     sdrx_decim_t* m_h[7][3];
+};
+
+// ---- float half-band decimators (dsp/decimatorsfi.h, decimatorsff.h, decimatorsif.h) over sdrx_fdecim_*.
+// FSample = the reference's {Real re; Real im} (dsptypes.h:67-87); define SDRX_HOST_FSAMPLE like SDRX_HOST_SAMPLE.
+#ifdef SDRX_HOST_FSAMPLE
+typedef SDRX_HOST_FSAMPLE FSample;
+#else
+struct FSample {
+    FSample() : m_real(0), m_imag(0) {}
+    FSample(float real, float imag = 0) : m_real(real), m_imag(imag) {}
+    float real() const { return m_real; }
+    float imag() const { return m_imag; }
+    void setReal(float v) { m_real = v; }
+    void setImag(float v) { m_imag = v; }
+    float m_real, m_imag;
+};
+#endif
+static_assert(sizeof(FSample) == 8, "FSample must be {float re, float im}");
+typedef std::vector<FSample> FSampleVector;
+
+// shared body: one handle per (K, fcPos) method, created on first use (as Decimators above)
+template<typename OutVec, typename InT, int IN_KIND, int OUT_KIND, int BITS>
+class FloatDecimatorsBase {
+public:
+    explicit FloatDecimatorsBase(int device = 0) : m_device(device) { for (auto& row : m_h) for (auto& h : row) h = nullptr; }
+    ~FloatDecimatorsBase() { for (auto& row : m_h) for (auto& h : row) if (h) sdrx_fdecim_destroy(h); }
+    FloatDecimatorsBase(const FloatDecimatorsBase&) = delete;
+    FloatDecimatorsBase& operator=(const FloatDecimatorsBase&) = delete;
+    void decimate1(typename OutVec::iterator* it, const InT* buf, int32_t nbIAndQ) { run(0, SDRX_FC_CEN, it, buf, nbIAndQ); }
+#define SDRX_FDECIM(K, L)                                                                                                     \
+    void decimate##K##_inf(typename OutVec::iterator* it, const InT* buf, int32_t nbIAndQ) { run(L, SDRX_FC_INF, it, buf, nbIAndQ); } \
+    void decimate##K##_sup(typename OutVec::iterator* it, const InT* buf, int32_t nbIAndQ) { run(L, SDRX_FC_SUP, it, buf, nbIAndQ); } \
+    void decimate##K##_cen(typename OutVec::iterator* it, const InT* buf, int32_t nbIAndQ) { run(L, SDRX_FC_CEN, it, buf, nbIAndQ); }
+    SDRX_FDECIM(2, 1) SDRX_FDECIM(4, 2) SDRX_FDECIM(8, 3) SDRX_FDECIM(16, 4) SDRX_FDECIM(32, 5) SDRX_FDECIM(64, 6)
+#undef SDRX_FDECIM
+private:
+    void run(int log2, int fcpos, typename OutVec::iterator* it, const InT* buf, int32_t n)
+    {
+        sdrx_fdecim_t*& h = m_h[log2][fcpos];
+        if (!h && sdrx_fdecim_create(&h, m_device, log2, fcpos, IN_KIND, OUT_KIND, BITS) != SDRX_OK) {
+            std::fprintf(stderr, "sdrx float decimators: %s\n", sdrx_last_error()); h = nullptr; return;
+        }
+        int32_t cnt = 0;
+        if (sdrx_fdecim_process(h, buf, n, &**it, &cnt) != SDRX_OK) { std::fprintf(stderr, "sdrx float decimators: %s\n", sdrx_last_error()); return; }
+        *it += cnt;
+    }
+    int m_device;
+    sdrx_fdecim_t* m_h[7][3];
+};
+// DecimatorsFI: float in, int16 Sample out (decimatorsfi.h:29-57; AirspyHF thread)
+class DecimatorsFI : public FloatDecimatorsBase<SampleVector, float, SDRX_FD_IN_F32, SDRX_FD_OUT_I16, 16> {
+public: explicit DecimatorsFI(int device = 0) : FloatDecimatorsBase(device) {}
+};
+// DecimatorsFF: float in, float FSample out (decimatorsff.h)
+class DecimatorsFF : public FloatDecimatorsBase<FSampleVector, float, SDRX_FD_IN_F32, SDRX_FD_OUT_F32, 16> {
+public: explicit DecimatorsFF(int device = 0) : FloatDecimatorsBase(device) {}
+};
+// DecimatorsIF<qint16, InputBits>: int16 in, float out scaled by decimation_scale<InputBits> (decimatorsif.h:52-79)
+template<typename T, unsigned InputBits>
+class DecimatorsIF : public FloatDecimatorsBase<FSampleVector, T, SDRX_FD_IN_I16, SDRX_FD_OUT_F32, (int)InputBits> {
+    static_assert(sizeof(T) == 2, "this build covers DecimatorsIF<qint16, {8,12,16}>");
+public: explicit DecimatorsIF(int device = 0) : FloatDecimatorsBase<FSampleVector, T, SDRX_FD_IN_I16, SDRX_FD_OUT_F32, (int)InputBits>(device) {}
 };
 
 // N DownChannelizers on one device stream.  configure() == DownChannelizer::configure(queue, rate, fc)

@@ -29,6 +29,7 @@
 uint32_t dropin_rng_state = 12345u;
 int dropin_fails = 0;
 void producer_side_u(int device);      // dropin_test_u.cpp
+void producer_side_f(int device);      // dropin_test_f.cpp
 
 namespace {
 
@@ -139,6 +140,7 @@ int main(int argc, char** argv)
     consumer_side(device);
     producer_side(device);
     producer_side_u(device);
+    producer_side_f(device);
     printf(dropin_fails ? "DROP-IN CHECK FAILED: %d mismatches\n" : "DROP-IN CHECK PASSED%.0d\n", dropin_fails);
     return dropin_fails ? 1 : 0;
 }
