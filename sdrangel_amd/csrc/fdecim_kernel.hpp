@@ -11,6 +11,10 @@
 // "4x downsample and rotate" front end (sums of 4 consecutive samples, association kept as written there) followed
 // by L-2 stages; L = 1, 2 _inf/_sup and decimate1 have no filter at all (fd_pointwise_kernel).
 //
+// Tried and not adopted (experiments/fdecim_wave_kernel.hpp.txt): a single-wave flavour (LDS-bandwidth bound: every lane
+// reads (R + 32) / R window entries per output) and giving the two components to different waves (R = 8 windows cost
+// 224 VGPRs, or spills under a launch bound).
+//
 // Work decomposition = decim_chain_kernel's: the stream that enters stage 1 ("pre-samples") is cut into chunks of
 // 2048; a workgroup owns a segment of consecutive chunks and carries every stage's 32-entry arm history in LDS from
 // chunk to chunk; before its first chunk it replays warm-up chunks (>= 62 * (2^NS - 1) pre-samples: the chain's
@@ -19,14 +23,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace sdrx {
 
 constexpr int FD_CHUNK = 2048;          // pre-samples per chunk
 constexpr int FD_THREADS = 256;
 constexpr int FD_H = 32;                // history entries kept in front of every arm (31 are read)
-
-struct FdCoef { float c[16]; };
 
 // front-end codes
 enum { FD_FE_ID = 0, FD_FE_INF4 = 1, FD_FE_SUP4_A = 2, FD_FE_SUP4_B = 3, FD_FE_INF2 = 4, FD_FE_SUP2 = 5 };
@@ -108,11 +111,33 @@ __device__ __forceinline__ void fd_store(void* out, long k, float2 v, int out_ki
     }
 }
 
+// order-64 half-band decimals (hbfiltertraits.cpp:173-190) narrowed to float like hbCoeffsF.  Compile-time
+// literals on purpose: on gfx950 a VALU op with an SGPR operand issues at half rate (profiles/r01_valu_issue_rates.txt).
+__host__ __device__ constexpr float fd_c(int i)
+{
+    constexpr double d[16] = {
+        -0.0004653050334792540416659067936677729449, 0.0007120490624526883919470643391491648799,
+        -0.0012303473710125558716887983479182366864, 0.0019716520179919017584369012041634050547,
+        -0.0029947484165425580261710170049127555103, 0.0043703902150498061263128590780979720876,
+        -0.0061858352927315653213558022116558277048, 0.0085554408639278121950777489246320328675,
+        -0.0116397924445187355563247066925214312505, 0.0156852221106748394852115069397768820636,
+        -0.0211070832238078286147153761476147337817, 0.0286850846890029896607554604770484729670,
+        -0.0400956173930921908055147184768429724500, 0.0597215923200692666572564348825835622847,
+        -0.1036982054813635201195864965484361164272, 0.3175014394028848885298543791577685624361,
+    };
+    return (float)d[i];
+}
+
+template<int I, int N, typename F> __device__ __forceinline__ void fd_static_for(F&& f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); fd_static_for<I + 1, N>(f); }
+}
+
 // R consecutive outputs (I and Q) of one stage for lane t.  Arm arrays hold O[j] / E[j] at index FD_H + j.
 template<int R>
 __device__ __forceinline__ void fd_stage(const float* __restrict__ oI, const float* __restrict__ oQ,
                                          const float* __restrict__ eI, const float* __restrict__ eQ,
-                                         int t, const FdCoef& cf, float (&yI)[R], float (&yQ)[R])
+                                         int t, float (&yI)[R], float (&yQ)[R])
 {
     const int b = R * t;                         // w[i] = O[k0 - 32 + i], k0 = R * t
     float wI[R + 32], wQ[R + 32], cI[R], cQ[R];
@@ -135,24 +160,24 @@ __device__ __forceinline__ void fd_stage(const float* __restrict__ oI, const flo
     }
 #pragma unroll
     for (int r = 0; r < R; r++) { cI[r] = eI[b + r + FD_H - 15]; cQ[r] = eQ[b + r + FD_H - 15]; }
-#pragma unroll
-    for (int r = 0; r < R; r++) {
+    fd_static_for<0, R>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
         float aI = 0.0f, aQ = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            aI = aI + (wI[32 + r - i] + wI[1 + r + i]) * cf.c[i];
-            aQ = aQ + (wQ[32 + r - i] + wQ[1 + r + i]) * cf.c[i];
-        }
+        fd_static_for<0, 16>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            aI = aI + (wI[32 + r - i] + wI[1 + r + i]) * fd_c(i);
+            aQ = aQ + (wQ[32 + r - i] + wQ[1 + r + i]) * fd_c(i);
+        });
         yI[r] = aI + cI[r] * 0.5f;
         yQ[r] = aQ + cQ[r] * 0.5f;
-    }
+    });
 }
 
 template<int NS, int IN>
 __global__ __launch_bounds__(FD_THREADS)
 void fdecim_chain_kernel(const float2* __restrict__ hist,   // fd_warm_chunks(NS) * FD_CHUNK pre-samples in front of the call
                          const void* __restrict__ in, void* __restrict__ out,
-                         long n_pre, long n_out, int n_chunks, int cps, int fe, int out_kind, float scale, FdCoef cf)
+                         long n_pre, long n_out, int n_chunks, int cps, int fe, int out_kind, float scale)
 {
     constexpr int C = FD_CHUNK, NT = FD_THREADS, WARM = fd_warm_chunks(NS);
     constexpr int PPT = C / 2 / NT;                        // pre-sample PAIRS per lane per chunk (4)
@@ -208,16 +233,16 @@ void fdecim_chain_kernel(const float2* __restrict__ hist,   // fd_warm_chunks(NS
             };
             if (s == 1) {
                 float yI[4], yQ[4];
-                fd_stage<4>(oI, oQ, eI, eQ, tid, cf, yI, yQ);
+                fd_stage<4>(oI, oQ, eI, eQ, tid, yI, yQ);
 #pragma unroll
                 for (int r = 0; r < 4; r++) emit(4 * tid + r, yI[r], yQ[r]);
             } else if (s == 2) {
                 float yI[2], yQ[2];
-                fd_stage<2>(oI, oQ, eI, eQ, tid, cf, yI, yQ);
+                fd_stage<2>(oI, oQ, eI, eQ, tid, yI, yQ);
                 emit(2 * tid, yI[0], yQ[0]); emit(2 * tid + 1, yI[1], yQ[1]);
             } else if (tid < NOUT) {
                 float yI[1], yQ[1];
-                fd_stage<1>(oI, oQ, eI, eQ, tid, cf, yI, yQ);
+                fd_stage<1>(oI, oQ, eI, eQ, tid, yI, yQ);
                 emit(tid, yI[0], yQ[0]);
             }
             __syncthreads();

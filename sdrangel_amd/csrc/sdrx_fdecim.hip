@@ -12,7 +12,7 @@ using namespace sdrx;
 
 namespace {
 
-typedef void (*fd_chain_fn)(const float2*, const void*, void*, long, long, int, int, int, int, float, FdCoef);
+typedef void (*fd_chain_fn)(const float2*, const void*, void*, long, long, int, int, int, int, float);
 
 template<int IN> fd_chain_fn chain_for(int ns)
 {
@@ -26,18 +26,6 @@ template<int IN> fd_chain_fn chain_for(int ns)
     }
     return nullptr;
 }
-
-// order-64 half-band decimals (hbfiltertraits.cpp:173-190), narrowed to float like hbCoeffsF
-const double HB64_DEC[16] = {
-    -0.0004653050334792540416659067936677729449, 0.0007120490624526883919470643391491648799,
-    -0.0012303473710125558716887983479182366864, 0.0019716520179919017584369012041634050547,
-    -0.0029947484165425580261710170049127555103, 0.0043703902150498061263128590780979720876,
-    -0.0061858352927315653213558022116558277048, 0.0085554408639278121950777489246320328675,
-    -0.0116397924445187355563247066925214312505, 0.0156852221106748394852115069397768820636,
-    -0.0211070832238078286147153761476147337817, 0.0286850846890029896607554604770484729670,
-    -0.0400956173930921908055147184768429724500, 0.0597215923200692666572564348825835622847,
-    -0.1036982054813635201195864965484361164272, 0.3175014394028848885298543791577685624361,
-};
 
 // elements (floats or int16) consumed per loop iteration of decimateK_x (decimatorsfi.cpp:23-779 `pos +=` strides)
 int fd_group(int log2, int fcpos)
@@ -70,7 +58,6 @@ struct sdrx_fdecim {
     int in_elem = 4, out_cplx_bytes = 4;
     float scale = 1.0f;
     int cus = 256;
-    FdCoef cf;
     fd_chain_fn chain = nullptr;
     hipStream_t own_stream = nullptr, stream = nullptr;
     float2* d_hist[2] = { nullptr, nullptr };
@@ -106,7 +93,7 @@ static int launch(sdrx_fdecim* h, const void* d_in, long n_groups, void* d_out, 
     const int cps = choose_cps(n_chunks, h->cus * wg_per_cu, warm);
     const long segs = (n_chunks + cps - 1) / cps;
     hipLaunchKernelGGL(h->chain, dim3((unsigned)segs), dim3(FD_THREADS), 0, h->stream,
-                       h->d_hist[h->cur], d_in, d_out, n_pre, n_out, (int)n_chunks, cps, h->fe, h->out_kind, h->scale, h->cf);
+                       h->d_hist[h->cur], d_in, d_out, n_pre, n_out, (int)n_chunks, cps, h->fe, h->out_kind, h->scale);
     SDRX_HIP(hipGetLastError());
     snprintf(h->last_name, sizeof h->last_name, "fdecim_chain_kernel<%d,%d>", h->ns, h->in_kind);
     h->last_grid = (int)segs; h->last_block = FD_THREADS; h->last_lds = lds;
@@ -149,7 +136,6 @@ int sdrx_fdecim_create(sdrx_fdecim_t** out, int device, int log2_decim, int fcpo
     }
     // DecimatorsIF: decimation_scale<InputBits>::scaleIn (decimatorsif.cpp)
     h->scale = in_kind == 1 ? (input_bits == 8 ? (float)(1.0 / 128.0) : input_bits == 12 ? (float)(1.0 / 2048.0) : (float)(1.0 / 32768.0)) : 1.0f;
-    for (int i = 0; i < 16; i++) h->cf.c[i] = (float)HB64_DEC[i];
     h->cus = device_cu_count(device);
     if (h->ns) h->chain = in_kind == 0 ? chain_for<0>(h->ns) : chain_for<1>(h->ns);
     hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
