@@ -161,7 +161,8 @@ typedef struct sdrx_backend_cfg {
     int32_t out_rate;        /* audio / demod rate; distance step = (Real) in_rate / (Real) out_rate; <= in_rate */
     float   interp_cutoff;   /* m_interpolator.create(16, in_rate, interp_cutoff, taps_per_phase) */
     float   taps_per_phase;  /* 4.5 (default, NFM) or 2.0 (SSB) */
-    int32_t filt_mode;       /* 0 none, 1 runFilt, 2 runSSB usb, 3 runSSB lsb, 4 runDSB  (getDC = true) */
+    int32_t filt_mode;       /* 0 none, 1 runFilt, 2 runSSB usb, 3 runSSB lsb, 4 runDSB  (getDC = true),
+                              * 5 runAsym usb, 6 runAsym lsb: fftfilt(f2, 2048) + create_asym_filter(fopp = f1, fin = f2) (atvdemod.cpp:262,647) */
     float   f1, f2;          /* modes 1-3: fftfilt(f1, f2, 1024); mode 4: fftfilt(f2, 2048) (DSBFilter, ssbdemod.cpp:92); normalised to the OUTPUT rate */
     int32_t discri;          /* 0 none, 1 phaseDiscriminatorDelta (NFM), 2 phaseDiscriminator (UDPSrc) */
     float   fm_scaling;      /* setFMScaling */

@@ -203,8 +203,9 @@ int64_t ref_backend_feed(void* h, const int16_t* iq, int64_t n_cplx, float* out_
 
 // fftfilt overlap-add SSB/complex filter (fftfilt.cpp:261-325)
 void* ref_fftfilt_new(float f1, float f2, int len) { return f1 < 0 ? new fftfilt(f2, len) : new fftfilt(f1, f2, len); }
+void* ref_fftfilt_new_asym(float fopp, float fin, int len) { fftfilt* f = new fftfilt(fin, len); f->create_asym_filter(fopp, fin); return f; }
 void ref_fftfilt_free(void* h) { delete static_cast<fftfilt*>(h); }
-// mode 0: runFilt, 1: runSSB usb, 2: runSSB lsb, 3: runDSB
+// mode 0: runFilt, 1: runSSB usb, 2: runSSB lsb, 3: runDSB, 4: runAsym usb, 5: runAsym lsb
 int64_t ref_fftfilt_run(void* h, int mode, const float* in_iq, int64_t n, float* out_iq)
 {
     fftfilt* f = static_cast<fftfilt*>(h);
@@ -213,7 +214,7 @@ int64_t ref_fftfilt_run(void* h, int mode, const float* in_iq, int64_t n, float*
         fftfilt::cmplx c(in_iq[2*i], in_iq[2*i+1]);
         fftfilt::cmplx* o = 0;
         int r = mode == 0 ? f->runFilt(c, &o) : mode == 1 ? f->runSSB(c, &o, true)
-              : mode == 2 ? f->runSSB(c, &o, false) : f->runDSB(c, &o);
+              : mode == 2 ? f->runSSB(c, &o, false) : mode == 3 ? f->runDSB(c, &o) : f->runAsym(c, &o, mode == 4);
         for (int k = 0; k < r; k++) { out_iq[2*n_out] = o[k].real(); out_iq[2*n_out+1] = o[k].imag(); n_out++; }
     }
     return n_out;

@@ -68,7 +68,10 @@ typedef struct sdro_fftfilt sdro_fftfilt;
 sdro_fftfilt* sdro_fftfilt_new(float f1, float f2, int32_t len);
 void    sdro_fftfilt_free(sdro_fftfilt*);
 const float* sdro_fftfilt_filter(const sdro_fftfilt*);                   /* len complex */
-/* mode 0 runFilt, 1 runSSB usb, 2 runSSB lsb, 3 runDSB (fftfilt.cpp:261-361) */
+/* fftfilt(fin, len) + create_asym_filter(fopp, fin) (fftfilt.cpp:172-225; ATV demod) */
+sdro_fftfilt* sdro_fftfilt_new_asym(float fopp, float fin, int32_t len);
+const float* sdro_fftfilt_filter_opp(const sdro_fftfilt*);               /* len complex */
+/* mode 0 runFilt, 1 runSSB usb, 2 runSSB lsb, 3 runDSB (fftfilt.cpp:261-361), 4 runAsym usb, 5 runAsym lsb (:363-402) */
 int64_t sdro_fftfilt_run(sdro_fftfilt*, int32_t mode, const float* in_iq, int64_t n, float* out_iq);
 
 /* kind 0: phaseDiscriminatorDelta (phasediscri.h:61-78); 1: phaseDiscriminator (:50-55) */

@@ -257,7 +257,7 @@ void sdro_gfft(float* iq, int32_t n, int32_t inverse)
 struct sdro_fftfilt {
     int flen, flen2, inptr;
     gfft g;
-    cf *filter, *data, *ovl, *out;
+    cf *filter, *filter_opp, *data, *ovl, *out;     /* filter_opp: create_asym_filter's opposite-band response */
 };
 
 static inline cf c_mul(cf a, cf b) { cf t; t.r = a.r * b.r - a.i * b.i; t.i = a.r * b.i + a.i * b.r; return t; }   /* std::complex<float> *= */
@@ -303,7 +303,31 @@ sdro_fftfilt* sdro_fftfilt_new(float f1, float f2, int32_t len)
     if (scale != 0) for (int i = 0; i < len; i++) { f->filter[i].r /= scale; f->filter[i].i /= scale; }
     return f;
 }
-void sdro_fftfilt_free(sdro_fftfilt* f) { if (f) { free(f->g.u); free(f->filter); free(f->data); free(f->ovl); free(f->out); free(f); } }
+/* low-pass design shared by create_dsb_filter and both halves of create_asym_filter (fftfilt.cpp:149-225):
+ * windowed sinc in the first flen2 bins, forward FFT, normalise to max |H| over bins 0..flen2-1 */
+static void design_lowpass(sdro_fftfilt* f, cf* dst, float fc)
+{
+    memset(dst, 0, sizeof(cf) * (size_t)f->flen);
+    for (int i = 0; i < f->flen2; i++) { const float w = blackman(i, f->flen2); dst[i].r = fsinc(fc, i, f->flen2) * w; dst[i].i = 0.0f * w; }
+    gfft_run(&f->g, dst, 0);
+    float scale = 0;
+    for (int i = 0; i < f->flen2; i++) { const float mag = hypotf(dst[i].r, dst[i].i); if (mag > scale) scale = mag; }
+    if (scale != 0) for (int i = 0; i < f->flen; i++) { dst[i].r /= scale; dst[i].i /= scale; }
+}
+
+/* fftfilt(fin, len) followed by create_asym_filter(fopp, fin) (atvdemod.cpp:647): in-band and opposite-band low passes */
+sdro_fftfilt* sdro_fftfilt_new_asym(float fopp, float fin, int32_t len)
+{
+    sdro_fftfilt* f = sdro_fftfilt_new(-1.0f, fin, len);
+    if (!f) return 0;
+    f->filter_opp = (cf*)calloc((size_t)len, sizeof(cf));
+    design_lowpass(f, f->filter, fin);
+    design_lowpass(f, f->filter_opp, fopp);
+    return f;
+}
+const float* sdro_fftfilt_filter_opp(const sdro_fftfilt* f) { return (const float*)f->filter_opp; }
+
+void sdro_fftfilt_free(sdro_fftfilt* f) { if (f) { free(f->g.u); free(f->filter); free(f->filter_opp); free(f->data); free(f->ovl); free(f->out); free(f); } }
 const float* sdro_fftfilt_filter(const sdro_fftfilt* f) { return (const float*)f->filter; }
 
 int64_t sdro_fftfilt_run(sdro_fftfilt* f, int32_t mode, const float* in, int64_t n, float* out)
@@ -321,6 +345,10 @@ int64_t sdro_fftfilt_run(sdro_fftfilt* f, int32_t mode, const float* in, int64_t
             f->data[0] = c_mul(f->data[0], f->filter[0]);
             if (mode == 1) for (int i = 1; i < h; i++) { f->data[i] = c_mul(f->data[i], f->filter[i]); f->data[h + i].r = 0; f->data[h + i].i = 0; }
             else           for (int i = 1; i < h; i++) { f->data[i].r = 0; f->data[i].i = 0; f->data[h + i] = c_mul(f->data[h + i], f->filter[h + i]); }
+        } else if (mode == 4 || mode == 5) {               /* runAsym (:363-402): DC always kept, bin flen2 left as it is */
+            f->data[0] = c_mul(f->data[0], f->filter[0]);
+            if (mode == 4) for (int i = 1; i < h; i++) { f->data[i] = c_mul(f->data[i], f->filter[i]); f->data[h + i] = c_mul(f->data[h + i], f->filter_opp[h + i]); }
+            else           for (int i = 1; i < h; i++) { f->data[i] = c_mul(f->data[i], f->filter_opp[i]); f->data[h + i] = c_mul(f->data[h + i], f->filter[h + i]); }
         } else {                                           /* runDSB (:327-361), getDC = true */
             for (int i = 0; i < h; i++) { f->data[i] = c_mul(f->data[i], f->filter[i]); f->data[h + i] = c_mul(f->data[h + i], f->filter[h + i]); }
         }

@@ -31,8 +31,8 @@ struct BeChan {                         // device resident: config + carried sta
     int ntaps;                          // taps per phase
     int phase_steps;
     int taps_off;                       // float offset into the taps table: [phase][ntaps]
-    int filt_mode;                      // 0 none, 1 runFilt, 2 runSSB usb, 3 runSSB lsb, 4 runDSB (fft length 2048)
-    int filt_off;                       // complex offset into the filter table (BE_FFT_MAX entries per channel)
+    int filt_mode;                      // 0 none, 1 runFilt, 2 runSSB usb, 3 runSSB lsb, 4 runDSB, 5 runAsym usb, 6 runAsym lsb (4..6: fft length 2048)
+    int filt_off;                       // complex offset into the filter table (2 * BE_FFT_MAX entries per channel: filter, filterOpp)
     int discri;                         // 0 none, 1 phaseDiscriminatorDelta, 2 phaseDiscriminator
     float fm_scaling;
     // --- state
@@ -371,7 +371,9 @@ void be_fft_kernel(const BeChan* __restrict__ ch, const BeBufs* __restrict__ buf
     for (int i = tid; i < H; i += NT) {
         float2 lo = ya[i], hi = ya[H + i];
         if (s.filt_mode == 1 || s.filt_mode == 4) { lo = c_mul(lo, filt[i]); hi = c_mul(hi, filt[H + i]); }   // runFilt / runDSB (getDC)
-        else if (i == 0) { lo = c_mul(lo, filt[0]); /* bin N/2 is left untouched (fftfilt.cpp:294-311) */ }
+        else if (i == 0) { lo = c_mul(lo, filt[0]); /* bin N/2 is left untouched (fftfilt.cpp:294-311, 374-392) */ }
+        else if (s.filt_mode == 5) { lo = c_mul(lo, filt[i]); hi = c_mul(hi, filt[BE_FFT_MAX + H + i]); }         // runAsym usb: lsb side through filterOpp
+        else if (s.filt_mode == 6) { lo = c_mul(lo, filt[BE_FFT_MAX + i]); hi = c_mul(hi, filt[H + i]); }         // runAsym lsb
         else if (s.filt_mode == 2) { lo = c_mul(lo, filt[i]); hi = make_float2(0.0f, 0.0f); }    // usb
         else { lo = make_float2(0.0f, 0.0f); hi = c_mul(hi, filt[H + i]); }                      // lsb
         xa[i] = lo; xa[H + i] = hi;

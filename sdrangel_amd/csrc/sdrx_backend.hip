@@ -101,7 +101,7 @@ static int ensure_capacity(sdrx_backend* b, int c, int64_t n_in)
     while (cap < n_in) cap *= 2;
     // pending (<512) + at most one resampler output per input (distance step >= 1 by construction of decimate())
     const size_t n_res_max = (size_t)cap + 1024;
-    const size_t half = h.cfg.filt_mode == 4 ? BE_FFT : BE_FFT / 2;
+    const size_t half = h.cfg.filt_mode >= 4 ? BE_FFT : BE_FFT / 2;
     const size_t n_blk_max = n_res_max / half + 2;
     // buffers that carry state (res: pending, tail: ovlbuf) must keep their content
     auto grow_keep = [&](DevBuf& buf, size_t bytes, size_t keep) -> int {
@@ -163,7 +163,7 @@ int sdrx_backend_create(sdrx_backend_t** out, int device, int32_t n_ch, const sd
     if (n_ch <= 0 || !cfg) { set_error("sdrx_backend_create: bad argument"); return SDRX_EINVAL; }
     for (int c = 0; c < n_ch; c++) {
         const sdrx_backend_cfg& k = cfg[c];
-        if (k.in_rate <= 0 || k.out_rate <= 0 || k.out_rate > k.in_rate || k.filt_mode < 0 || k.filt_mode > 4 ||
+        if (k.in_rate <= 0 || k.out_rate <= 0 || k.out_rate > k.in_rate || k.filt_mode < 0 || k.filt_mode > 6 ||
             k.discri < 0 || k.discri > 2 || k.taps_per_phase <= 0 || k.taps_per_phase * 16 > BE_HIST) {
             set_error("sdrx_backend_create: bad channel configuration (need out_rate <= in_rate, taps_per_phase*16 <= 256)");
             return SDRX_EINVAL;
@@ -197,8 +197,8 @@ int sdrx_backend_create(sdrx_backend_t** out, int device, int32_t n_ch, const sd
     }
 
     // per channel design
-    BE_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_filters), (size_t)n_ch * BE_FFT_MAX * 8));
-    b->filters_all.assign((size_t)n_ch * BE_FFT_MAX * 2, 0.0f);
+    BE_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_filters), (size_t)n_ch * 2 * BE_FFT_MAX * 8));   // [filter | filterOpp] per channel
+    b->filters_all.assign((size_t)n_ch * 2 * BE_FFT_MAX * 2, 0.0f);
     for (int c = 0; c < n_ch; c++) {
         const sdrx_backend_cfg& k = cfg[c];
         ChanHost& h = b->ch[(size_t)c];
@@ -218,15 +218,17 @@ int sdrx_backend_create(sdrx_backend_t** out, int device, int32_t n_ch, const sd
             b->taps_all.insert(b->taps_all.end(), poly.begin(), poly.end());
         }
         const int nt = b->ntaps[(size_t)c];
-        b->filt_off[(size_t)c] = c * BE_FFT_MAX;
-        const int flen = k.filt_mode == 4 ? BE_FFT_MAX : BE_FFT;
-        if (k.filt_mode) {
-            // fftfilt::create_filter / create_dsb_filter: windowed sinc in the first flen2 bins, forward FFT (on the GPU,
-            // with the same kernel code the data path uses), normalise to max |H| over bins 0..flen2-1
+        b->filt_off[(size_t)c] = c * 2 * BE_FFT_MAX;
+        const int flen = k.filt_mode >= 4 ? BE_FFT_MAX : BE_FFT;          // runDSB / runAsym: "double the FFT size used for SSB"
+        // fftfilt::create_filter / create_dsb_filter / create_asym_filter: windowed sinc in the first flen2 bins, forward FFT
+        // (on the GPU, with the same kernel code the data path uses), normalise to max |H| over bins 0..flen2-1.
+        // which: 0 = filter, 1 = filterOpp (runAsym only: low pass at f1 = the opposite band's width)
+        auto design = [&](int which) -> int {
             std::vector<float> f((size_t)flen * 2, 0.0f);
             const int h2 = flen / 2;
-            if (k.filt_mode == 4) {
-                for (int i = 0; i < h2; i++) f[(size_t)(2 * i)] = fsinc(k.f2, i, h2);            // fftfilt(f2, len): low pass only
+            if (k.filt_mode >= 4) {
+                const float fc = which ? k.f1 : k.f2;                                            // fftfilt(f2, len) / create_asym_filter(fopp = f1, fin = f2)
+                for (int i = 0; i < h2; i++) f[(size_t)(2 * i)] = fsinc(fc, i, h2);
             } else {
                 const bool lp = k.f2 != 0, hp = k.f1 != 0;
                 for (int i = 0; i < h2; i++) {
@@ -238,18 +240,24 @@ int sdrx_backend_create(sdrx_backend_t** out, int device, int32_t n_ch, const sd
                 if (hp && k.f2 < k.f1) f[(size_t)(2 * (h2 / 2))] += 1;
             }
             for (int i = 0; i < h2; i++) { const float w = blackman(i, h2); f[(size_t)(2 * i)] *= w; f[(size_t)(2 * i + 1)] *= w; }
-            float2* dst = b->d_filters + (size_t)c * BE_FFT_MAX;
-            BE_TRY(hipMemcpy(dst, f.data(), (size_t)flen * 8, hipMemcpyHostToDevice));
+            float2* dst = b->d_filters + (size_t)c * 2 * BE_FFT_MAX + (size_t)which * BE_FFT_MAX;
+            SDRX_HIP(hipMemcpy(dst, f.data(), (size_t)flen * 8, hipMemcpyHostToDevice));
             if (flen == BE_FFT) hipLaunchKernelGGL(be_fft_design_kernel<BE_FFT>, dim3(1), dim3(BE_FFT / 8), 0, b->stream, dst, b->d_utbl);
             else hipLaunchKernelGGL(be_fft_design_kernel<BE_FFT_MAX>, dim3(1), dim3(BE_FFT_MAX / 8), 0, b->stream, dst, b->d_utbl2);
-            BE_TRY(hipGetLastError());
-            BE_TRY(hipStreamSynchronize(b->stream));
-            BE_TRY(hipMemcpy(f.data(), dst, (size_t)flen * 8, hipMemcpyDeviceToHost));
+            SDRX_HIP(hipGetLastError());
+            SDRX_HIP(hipStreamSynchronize(b->stream));
+            SDRX_HIP(hipMemcpy(f.data(), dst, (size_t)flen * 8, hipMemcpyDeviceToHost));
             float scale = 0;
             for (int i = 0; i < h2; i++) { const float mag = hypotf(f[(size_t)(2 * i)], f[(size_t)(2 * i + 1)]); if (mag > scale) scale = mag; }
             if (scale != 0) for (int i = 0; i < flen * 2; i++) f[(size_t)i] /= scale;
-            BE_TRY(hipMemcpy(dst, f.data(), (size_t)flen * 8, hipMemcpyHostToDevice));
-            std::memcpy(&b->filters_all[(size_t)c * BE_FFT_MAX * 2], f.data(), (size_t)flen * 8);
+            SDRX_HIP(hipMemcpy(dst, f.data(), (size_t)flen * 8, hipMemcpyHostToDevice));
+            std::memcpy(&b->filters_all[((size_t)c * 2 + (size_t)which) * BE_FFT_MAX * 2], f.data(), (size_t)flen * 8);
+            return SDRX_OK;
+        };
+        if (k.filt_mode) {
+            int drc = design(0);
+            if (!drc && k.filt_mode >= 5) drc = design(1);
+            if (drc) { sdrx_backend_destroy(b); return drc; }
             (flen == BE_FFT ? b->any1024 : b->any2048) = true;
         }
         BeChan& s = b->h_chan[(size_t)c];
@@ -418,7 +426,7 @@ int sdrx_backend_get_design(sdrx_backend_t* b, int32_t c, int32_t* ntaps_per_pha
     const int nt = b->ntaps[(size_t)c];
     if (ntaps_per_phase) *ntaps_per_phase = nt;
     if (taps) std::memcpy(taps, &b->taps_all[(size_t)b->taps_off[(size_t)c]], (size_t)std::min(taps_cap, nt * 16) * 4);
-    if (filter_iq) std::memcpy(filter_iq, &b->filters_all[(size_t)c * BE_FFT_MAX * 2], BE_FFT_MAX * 8);
+    if (filter_iq) std::memcpy(filter_iq, &b->filters_all[(size_t)c * 2 * BE_FFT_MAX * 2], BE_FFT_MAX * 8);
     if (nco_inc) *nco_inc = b->h_chan[(size_t)c].nco_inc;
     return SDRX_OK;
 }

@@ -76,6 +76,7 @@ def _sig_float(L):
     L.sdro_backend_taps.restype = C.POINTER(C.c_float); L.sdro_backend_taps.argtypes = [vp]
     L.sdro_gfft.argtypes = [vp, i32, i32]
     L.sdro_fftfilt_new.restype = vp; L.sdro_fftfilt_new.argtypes = [f32, f32, i32]
+    L.sdro_fftfilt_new_asym.restype = vp; L.sdro_fftfilt_new_asym.argtypes = [f32, f32, i32]
     L.sdro_fftfilt_free.argtypes = [vp]
     L.sdro_fftfilt_filter.restype = C.POINTER(C.c_float); L.sdro_fftfilt_filter.argtypes = [vp]
     L.sdro_fftfilt_run.restype = i64; L.sdro_fftfilt_run.argtypes = [vp, i32, vp, i64, vp]
@@ -112,8 +113,8 @@ class Backend:
         L = lib(); _sig_float(L)
         self.L = L
         self.b = L.sdro_backend_new(float(nco_freq), float(in_rate), float(out_rate), 16, cutoff, tpp)
-        self.flen = 2048 if filt_mode == 4 else 1024
-        self.f = (L.sdro_fftfilt_new(-1.0, f2, 2048) if filt_mode == 4 else L.sdro_fftfilt_new(f1, f2, 1024)) if filt_mode else None
+        self.flen = 2048 if filt_mode >= 4 else 1024
+        self.f = (L.sdro_fftfilt_new_asym(f1, f2, 2048) if filt_mode >= 5 else L.sdro_fftfilt_new(-1.0, f2, 2048) if filt_mode == 4 else L.sdro_fftfilt_new(f1, f2, 1024)) if filt_mode else None
         self.filt_mode, self.discri, self.fm = filt_mode, discri, fm_scaling
         self.last = None      # last sample seen by the discriminator (carried state)
         self.prev_tail = np.zeros(0, np.float32)

@@ -35,6 +35,9 @@ CFGS = [
     dict(in_rate=48000, nco_freq=-12000, out_rate=48000, interp_cutoff=10000.0, taps_per_phase=2.0, filt_mode=0, f1=0.0, f2=0.0, discri=1, fm_scaling=5.0),
     # DSB mode of the SSB demod: fftfilt(2*bw/rate, 2048).runDSB (ssbdemod.cpp:92,167)
     dict(in_rate=60000, nco_freq=2500, out_rate=48000, interp_cutoff=6000.0, taps_per_phase=2.0, filt_mode=4, f1=0.0, f2=2 * 3000 / 48000, discri=0, fm_scaling=1.0),
+    # ATV demod's vestigial-sideband filter: fftfilt(fin, 2048) + create_asym_filter(fopp, fin), runAsym usb / lsb (atvdemod.cpp:262,647)
+    dict(in_rate=60000, nco_freq=-1500, out_rate=48000, interp_cutoff=9000.0, taps_per_phase=2.0, filt_mode=5, f1=0.04, f2=0.35, discri=0, fm_scaling=1.0),
+    dict(in_rate=60000, nco_freq=800, out_rate=48000, interp_cutoff=9000.0, taps_per_phase=2.0, filt_mode=6, f1=0.15, f2=0.08, discri=0, fm_scaling=1.0),
     # 62500 / 48000 is not a dyadic step: `distance += step` rounds on most emissions (the schedule recurrence must follow the float bits)
     dict(in_rate=62500, nco_freq=-9100, out_rate=48000, interp_cutoff=12500 / 2.2, taps_per_phase=4.5, filt_mode=0, f1=0.0, f2=0.0, discri=1, fm_scaling=24.0),
     dict(in_rate=250000, nco_freq=31000, out_rate=44100, interp_cutoff=9000.0, taps_per_phase=4.5, filt_mode=2, f1=300 / 44100, f2=3000 / 44100, discri=0, fm_scaling=1.0),
@@ -61,7 +64,7 @@ def test_design_products_match_oracle():
 def test_streaming_feeds_match_oracle():
     pairs = [mk(c) for c in CFGS]
     bank = sa.BackendBank([p[0] for p in pairs])
-    n_total = [40000, 90000, 40000, 30000, 60000, 20000, 25000, 50000, 70001, 131072]
+    n_total = [40000, 90000, 40000, 30000, 60000, 20000, 25000, 50000, 45000, 52000, 70001, 131072]
     xs = [synth.mix(n, 700 + i, 12000, 6000, 1 + i % 3) for i, n in enumerate(n_total)]
     # ragged feeds, different per channel, including empty and 1-sample ones
     cut_frac = [0.0, 0.00005, 0.013, 0.013, 0.41, 0.4101, 0.77, 1.0]

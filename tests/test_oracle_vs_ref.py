@@ -158,3 +158,23 @@ def test_float_decimators_fi_ff_if_random_blocks():
                     got = o.process(x)
                     assert got.size == 2 * n and np.array_equal(got.view(np.uint8), want[: 2 * n].view(np.uint8)), (kind, bits, log2, fc, blk)
                 L_.ref_fdecim_free(h)
+
+
+def test_fftfilt_run_asym_vestigial_sideband():
+    """fftfilt(fin, 2048) + create_asym_filter(fopp, fin) + runAsym usb/lsb (fftfilt.cpp:172-225, 363-402; ATV demod) vs the oracle"""
+    R = C.CDLL(REF); O = orc.lib(); orc._sig_float(O)
+    vp, f32 = C.c_void_p, C.c_float
+    R.ref_fftfilt_new_asym.restype = vp; R.ref_fftfilt_new_asym.argtypes = [f32, f32, C.c_int]
+    R.ref_fftfilt_run.restype = C.c_int64; R.ref_fftfilt_run.argtypes = [vp, C.c_int, vp, C.c_int64, vp]
+    R.ref_fftfilt_free.argtypes = [vp]
+    rng = np.random.default_rng(11)
+    x = rng.normal(0, 3000, 2 * 9000).astype(np.float32)
+    for mode in (4, 5):
+        for fopp, fin in ((0.05, 0.4), (0.2, 0.1)):
+            ho = O.sdro_fftfilt_new_asym(fopp, fin, 2048); hr = R.ref_fftfilt_new_asym(fopp, fin, 2048)
+            for a, b in ((0, 1000), (1000, 5000), (5000, 9000)):
+                seg = np.ascontiguousarray(x[2 * a: 2 * b]); ya = np.zeros(seg.size + 4096, np.float32); yb = ya.copy()
+                na = O.sdro_fftfilt_run(ho, mode, seg.ctypes.data, b - a, ya.ctypes.data)
+                nb = R.ref_fftfilt_run(hr, mode, seg.ctypes.data, b - a, yb.ctypes.data)
+                assert na == nb and np.array_equal(ya.view(np.uint32), yb.view(np.uint32)), (mode, fopp, fin, a, b)
+            O.sdro_fftfilt_free(ho); R.ref_fftfilt_free(hr)
