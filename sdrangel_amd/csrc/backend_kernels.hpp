@@ -46,6 +46,12 @@ struct BeChan {                         // device resident: config + carried sta
     int n_blocks;                       // complete fftfilt blocks of this feed       (written by be_schedule)
     int n_out;                          // samples in the output buffer after this feed
     int half;                           // fftfilt block = flen / 2: 512, or 1024 for runDSB
+    // --- dyadic resampling ratio (step * 2^dy_q is an integer; dy_q < 0: not dyadic): closed-form schedule
+    int dy_q, dy_S;                     // config: Q = 1 << dy_q, S = step * Q
+    int dy_active;                      // per feed: 1 = this feed's schedule comes from the closed form (be_sched_dyadic_*)
+    int dy_mode;                        //   0: k_j = dy_kb + ((dy_P0 + j*S) >> q), d_j = ((dy_P0 + j*S) & (Q-1)) / Q;  1 (S == Q, d < 1): k_j = dy_kb + j, d_j = dy_P0 / Q
+    int dy_pre, dy_cnt;                 //   entries written one by one in front (start-up, d < 1) / entries of the closed form
+    int dy_kb, dy_P0;
 };
 
 struct BeBufs {                         // per channel device pointers (per feed capacity ensured by the host)
@@ -98,7 +104,9 @@ __global__ void __launch_bounds__(64) be_schedule_kernel(BeChan* __restrict__ ch
     const int c = perm[c_raw < n_ch ? c_raw : n_ch - 1];   // surplus lanes shadow the last column (same values to the same addresses)
     BeChan& s = ch[c];
     const long stride = bufs[c].sched_stride;
-    const int n_in = (int)bufs[c].n_in;                     // < 2^28
+    const bool mine = !s.dy_active;                         // the closed-form kernels own dyadic channels (decided per feed by be_sched_dyadic_prep)
+    const int n_in_real = (int)bufs[c].n_in;                // < 2^28
+    const int n_in = mine ? n_in_real : 0;
     const float step = s.step;
     BeSchedLane l; l.d = s.distance; l.k = -1; l.p = bufs[c].sched;     // d: value BEFORE the next input's `-= 1.0`
     uint2* const p0 = l.p;
@@ -130,12 +138,96 @@ __global__ void __launch_bounds__(64) be_schedule_kernel(BeChan* __restrict__ ch
         }
         if (done) break;
     }
-    if (c_raw >= n_ch) return;
+    if (c_raw >= n_ch || !mine) return;
     s.n_in = n_in;
     s.distance = l.d - (float)(n_in - 1 - l.k);             // inputs consumed without an emission: each `-= 1.0` exact (d stays >= 1)
     const int cnt = (int)((l.p - p0) / stride);
     s.n_res = cnt;
     s.n_blocks = s.filt_mode ? (s.pending + cnt) / s.half : 0;
+}
+
+// ---- 1b. the same schedule in closed form when the ratio is dyadic (60000/48000 = 1.25, 120000/48000 = 2.5, 75000/48000 =
+// 25/16 ...: every channelizer output rate that is 48 kHz times a dyadic number).  With Q = 2^q, S = step * Q and the
+// distance on the 1/Q grid (it starts at 0 and every operation below keeps it there), all of the reference's float
+// operations are exact, so integer arithmetic reproduces them bit for bit.  In D = d * Q:
+//     emission: m = D >= Q ? D >> q : 1;  k += m;  D_post = D - m * Q;  entry {k, D_post / Q};  D = D_post + S.
+// Once D >= Q it stays so (S >= Q), and with P_0 = D mod Q, kb = index of the first such emission:
+//     k_j = kb + floor((P_0 + j * S) / Q),   d_j = ((P_0 + j * S) mod Q) / Q          (the floor sum telescopes)
+// so the emissions are independent of each other: `prep` (one lane per channel) walks the start-up emissions (d < 1, at
+// most Q + |D| of them), solves for the count and the end state; `fill` writes the entries in parallel.  A distance
+// that is not on the grid (never seen; a guard) hands the channel to the serial kernel for this feed.
+__global__ void be_sched_dyadic_prep_kernel(BeChan* __restrict__ ch, const BeBufs* __restrict__ bufs, const int* __restrict__ perm, int n_ch)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= n_ch) return;
+    const int c = perm[col];
+    BeChan& s = ch[c];
+    s.dy_active = 0;
+    if (s.dy_q < 0) return;
+    const int q = s.dy_q;
+    const long Q = 1L << q, S = s.dy_S;
+    const float d0 = s.distance;
+    long D = (long)(d0 * (float)Q);                         // exact when d0 is on the grid
+    if ((float)D / (float)Q != d0 || D > (1L << 40) || D < -(1L << 40)) return;
+    const long n_in = bufs[c].n_in;
+    uint2* p = bufs[c].sched;
+    const long stride = bufs[c].sched_stride;
+    long k = -1; int pre = 0;
+    bool ended = false;
+    while (D < Q && S != Q) {                               // start-up: one input per emission until the distance passes 1
+        if (k + 1 >= n_in) { ended = true; break; }
+        k += 1; D -= Q;
+        *p = make_uint2((uint32_t)k, __float_as_uint((float)D / (float)Q)); p += stride; pre++;
+        D += S;
+    }
+    long cnt = 0, kb = 0, P0 = 0; int mode = 0;
+    if (!ended) {
+        if (D < Q) {                                        // S == Q and d < 1: one input per emission for ever, constant distance
+            mode = 1; kb = k + 1; P0 = D - Q;
+            cnt = n_in - 1 - k; if (cnt < 0) cnt = 0;
+            k += cnt;                                       // D unchanged: (D - Q) + S = D
+        } else {
+            const long m0 = D >> q;
+            P0 = D & (Q - 1); kb = k + m0;
+            if (kb <= n_in - 1) {
+                const long R = n_in - 1 - kb;
+                const long J = (R * Q + Q - 1 - P0) / S;
+                cnt = J + 1;
+                k = kb + ((P0 + J * S) >> q);
+                D = ((P0 + J * S) & (Q - 1)) + S;
+            }
+        }
+    }
+    D -= (n_in - 1 - k) * Q;                                // inputs consumed without an emission: each `-= 1.0` exact
+    s.dy_active = 1; s.dy_mode = mode; s.dy_pre = pre; s.dy_cnt = (int)cnt; s.dy_kb = (int)kb; s.dy_P0 = (int)P0;
+    s.n_in = (int)n_in;
+    s.distance = (float)D / (float)Q;
+    s.n_res = pre + (int)cnt;
+    s.n_blocks = s.filt_mode ? (s.pending + s.n_res) / s.half : 0;
+}
+
+// 64 columns x 4 rows per workgroup; a lane writes 64 consecutive entries of its column, so every store instruction of a
+// wave covers 64 neighbouring columns of one schedule row (512 contiguous bytes)
+__global__ void __launch_bounds__(256) be_sched_dyadic_fill_kernel(const BeChan* __restrict__ ch, const BeBufs* __restrict__ bufs,
+                                                                   const int* __restrict__ perm, int n_ch)
+{
+    const int col = blockIdx.y * 64 + (threadIdx.x & 63);
+    if (col >= n_ch) return;
+    const BeChan& s = ch[perm[col]];
+    if (!s.dy_active) return;
+    const int q = s.dy_q, mode = s.dy_mode, cnt = s.dy_cnt;
+    const long Q = 1L << q, S = s.dy_S, P0 = s.dy_P0, kb = s.dy_kb;
+    uint2* __restrict__ base = bufs[perm[0]].sched + col;   // bank-wide base (column 0) + this column
+    const long j0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    const float inv = 1.0f / (float)Q;                      // a power of two: the product below is the exact quotient
+    for (int i = 0; i < 64; i++) {
+        const long j = j0 + i;
+        if (j >= cnt) break;
+        const long t = P0 + j * S;
+        const uint32_t k = mode ? (uint32_t)(kb + j) : (uint32_t)(kb + (t >> q));
+        const float d = mode ? (float)P0 * inv : (float)(t & (Q - 1)) * inv;
+        base[(long)(s.dy_pre + j) * n_ch] = make_uint2(k, __float_as_uint(d));
+    }
 }
 
 // ---- 2a. NCO mix of history + new samples into float (exact: int16 -> float, complex product)

@@ -86,6 +86,7 @@ struct sdrx_backend {
     float* d_nco = nullptr; float* d_taps = nullptr; float2* d_filters = nullptr;
     float* d_utbl = nullptr; float* d_utbl2 = nullptr;     // g_fft cosine tables for N = 1024 / 2048
     bool any1024 = false, any2048 = false;
+    bool any_dyadic = false;      // some resampling ratio has a closed-form schedule
     std::vector<float> taps_all; std::vector<float> filters_all;     // kept for inspection (tests)
     std::vector<int> taps_off, filt_off, ntaps;
     std::vector<int> perm, col_of;    // schedule column q holds channel perm[q]; col_of[c] is its inverse
@@ -264,9 +265,16 @@ int sdrx_backend_create(sdrx_backend_t** out, int device, int32_t n_ch, const sd
         std::memset(&s, 0, sizeof s);
         s.nco_inc = (int)(((float)k.nco_freq * BE_NCO_N) / (float)k.in_rate);          // NCO::setFreq (float math, truncation)
         s.step = (float)k.in_rate / (float)k.out_rate;
+        s.dy_q = -1; s.dy_S = 0;
+        if (s.step >= 1.0f && !getenv("SDRX_BE_SERIAL_SCHEDULE"))
+            for (int q = 0; q <= 10; q++) {
+                const float v = s.step * (float)(1 << q);                                  // exact (power of two)
+                if (v == std::floor(v) && v < (float)(1 << 20)) { s.dy_q = q; s.dy_S = (int)v; break; }
+            }
         s.ntaps = nt; s.phase_steps = 16;
         s.taps_off = b->taps_off[(size_t)c]; s.filt_mode = k.filt_mode; s.filt_off = b->filt_off[(size_t)c];
         s.discri = k.discri; s.fm_scaling = k.fm_scaling;
+        if (s.dy_q >= 0) b->any_dyadic = true;
         s.half = flen / 2;
         for (int i = 0; i < 2; i++) {
             BE_TRY(hipMalloc(reinterpret_cast<void**>(&h.hist[i]), BE_HIST * 4));
@@ -331,6 +339,15 @@ static int feed_common(sdrx_backend* b, const int16_t* const* d_iq, const int64_
     SDRX_HIP(hipMemcpyAsync(b->d_bufs, b->h_bufs, (size_t)b->n_ch * sizeof(BeBufs), hipMemcpyHostToDevice, b->stream));
     SDRX_HIP(hipEventRecord(b->bufs_ev, b->stream));
     const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, (n_max + BE_HIST + 255) / 256));
+    // closed-form schedule for dyadic ratios (prep decides per channel and feed), the serial walk for the rest
+    hipLaunchKernelGGL(be_sched_dyadic_prep_kernel, dim3((unsigned)((b->n_ch + 63) / 64)), dim3(64), 0, b->stream, b->d_chan, b->d_bufs, b->d_perm, b->n_ch);
+    SDRX_HIP(hipGetLastError());
+    if (b->any_dyadic) {
+        hipLaunchKernelGGL(be_sched_dyadic_fill_kernel, dim3((unsigned)((n_res_bound + 255) / 256), (unsigned)((b->n_ch + 63) / 64)), dim3(256), 0,
+                           b->stream, b->d_chan, b->d_bufs, b->d_perm, b->n_ch);
+        SDRX_HIP(hipGetLastError());
+    }
+    // always launched: lanes whose channel the closed form took exit at once (prep's off-grid guard can hand a channel back)
     hipLaunchKernelGGL(be_schedule_kernel, dim3((unsigned)((b->n_ch + 63) / 64)), dim3(64), 0, b->stream, b->d_chan, b->d_bufs, b->d_perm, b->n_ch);
     SDRX_HIP(hipGetLastError());
     if (producer && producer != b->stream) {

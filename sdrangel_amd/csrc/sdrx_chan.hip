@@ -322,6 +322,9 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
         g->subtrees.push_back(st);
         if ((int)g->passes.size() <= pass) g->passes.resize(pass + 1);
         g->passes[pass].push_back((int)si);
+        if (getenv("SDRX_CHAN_DEBUG"))
+            fprintf(stderr, "sdrx plan: pass %d stream %d (trie node %d, depth %d): %d levels, %d entries, %d arrays, %d LDS dwords (regions %d + %d)\n",
+                    pass, (int)si, root, g->streams[si].depth, levels, rel_nodes, st.n_arrays, st.lds_dwords, reg_size[0], reg_size[1]);
     }
 
     // device: histories + static tables
