@@ -6,6 +6,8 @@
 //       spans through BasebandSampleSink::feed(); the recorded samples and the MsgChannelizerNotification
 //       (rate, offset) each demod would have received must be identical.  One channel is re-configured
 //       in the middle of the stream.
+//   (3) the chain device thread -> Decimators -> SampleSinkFifo -> a DSPDeviceSourceEngine::work-shaped drain loop ->
+//       channelizers -> demod sinks, reference objects on one side, sdrx::Decimators + the GPU bank on the other.
 //   (2) producer side: the reference's Decimators<qint32,qint16,SDR_RX_SAMP_SZ,12> next to
 //       sdrx::Decimators<...> (include/sdrx/dsp.hpp) with the device thread's call pattern
 //       (limesdrinputthread.cpp:103-135): decimateK_x(&it, buf, len) into a SampleVector, block by block.
@@ -21,6 +23,7 @@
 #include "dsp/dspcommands.h"
 #include "dsp/decimators.h"
 #include "util/messagequeue.h"
+#include "dsp/samplesinkfifo.h"
 #include "gpudownchannelizerbank.h"
 #define SDRX_HOST_SAMPLE ::Sample      // sdrx::Decimators then takes the reference's SampleVector::iterator*
 #include "sdrx/dsp.hpp"
@@ -132,6 +135,73 @@ void producer_side(int device)
     PRODUCER(RefDec16, GpuDec16, qint16, decimate4_inf, -32768, 65536)      // full-scale 16-bit source
 }
 
+// (3) the whole RX chain as the application runs it: device-thread blocks -> Decimators::decimate8_cen -> the reference's
+// SampleSinkFifo::write -> a drain loop shaped like DSPDeviceSourceEngine::work (dspdevicesourceengine.cpp:325-408:
+// readBegin -> up to two spans -> every sink's feed() -> readCommit) -> channelizers -> demod sinks.  Left: reference
+// objects only.  Right: sdrx::Decimators + GpuDownChannelizerBank behind the same FIFO class and the same loop.
+void engine_chain(int device)
+{
+    const int fsDev = 8 * 2400000, fs = 2400000, N = 6;
+    Decimators<qint32, qint16, SDR_RX_SAMP_SZ, 12> refDec;
+    sdrx::Decimators<qint32, qint16, SDR_RX_SAMP_SZ, 12> gpuDec(device);
+    SampleSinkFifo refFifo(fs / 4), gpuFifo(fs / 4);      // small on purpose: the ring wraps, work() sees two-part reads
+    std::vector<RecorderSink*> refSinks, gpuSinks;
+    std::vector<DownChannelizer*> refs;
+    GpuDownChannelizerBank bank(device);
+    for (int c = 0; c < N; c++) {
+        refSinks.push_back(new RecorderSink); gpuSinks.push_back(new RecorderSink);
+        refs.push_back(new DownChannelizer(refSinks[c])); bank.addChannel(gpuSinks[c]);
+    }
+    DSPSignalNotification sig(fs, 435000000);
+    for (int c = 0; c < N; c++) refs[c]->handleMessage(sig);
+    bank.handleMessage(sig);
+    for (int c = 0; c < N; c++) {
+        const int rate = c == 3 ? 96000 : 48000, fc = -1000000 + c * 400000 + 1234;
+        DSPConfigureChannelizer cfg(rate, fc);
+        refs[c]->handleMessage(cfg); bank.configureChannel(c, rate, fc);
+    }
+    (void) fsDev;
+    struct Drain {
+        static void work(SampleSinkFifo& fifo, std::vector<BasebandSampleSink*>& sinks)
+        {
+            while (fifo.fill() > 0) {
+                SampleVector::iterator p1b, p1e, p2b, p2e;
+                const uint count = fifo.readBegin(fifo.fill(), &p1b, &p1e, &p2b, &p2e);
+                if (p1b != p1e) for (size_t i = 0; i < sinks.size(); i++) sinks[i]->feed(p1b, p1e, false);
+                if (p2b != p2e) for (size_t i = 0; i < sinks.size(); i++) sinks[i]->feed(p2b, p2e, false);
+                fifo.readCommit(count);
+            }
+        }
+    };
+    std::vector<BasebandSampleSink*> refEngineSinks(refs.begin(), refs.end()), gpuEngineSinks(1, &bank);
+    const int block = 2 * 131072;                           // int16 per device callback
+    std::vector<qint16> buf((size_t) block);
+    SampleVector convR((size_t) block / 2), convG((size_t) block / 2);
+    long fed = 0;
+    for (int b = 0; b < 40; b++) {
+        const int len = (b % 5 == 2) ? block - 14 : block;
+        for (int i = 0; i < len; i++) buf[i] = (qint16)((int)(rng() % 4096) - 2048);
+        SampleVector::iterator itR = convR.begin(), itG = convG.begin();
+        refDec.decimate8_cen(&itR, buf.data(), len);        // the device thread's callback (limesdrinputthread.cpp:103-135)
+        gpuDec.decimate8_cen(&itG, buf.data(), len);
+        refFifo.write(convR.begin(), itR);
+        gpuFifo.write(convG.begin(), itG);
+        fed += itR - convR.begin();
+        if (b % 3 != 1) { Drain::work(refFifo, refEngineSinks); Drain::work(gpuFifo, gpuEngineSinks); }   // sometimes two blocks pile up
+    }
+    Drain::work(refFifo, refEngineSinks); Drain::work(gpuFifo, gpuEngineSinks);
+    for (int c = 0; c < N; c++) {
+        char what[96];
+        const std::vector<Sample>& a = refSinks[c]->got; const std::vector<Sample>& g = gpuSinks[c]->got;
+        bool same = a.size() == g.size() && !a.empty();
+        for (size_t i = 0; same && i < a.size(); i++) same = a[i].real() == g[i].real() && a[i].imag() == g[i].imag();
+        snprintf(what, sizeof what, "engine chain: decimate8_cen -> FIFO -> work() -> channel %d", c);
+        report(what, same, (long) a.size());
+    }
+    printf("engine chain: %ld samples through the FIFO\n", fed);
+    for (int c = 0; c < N; c++) delete refs[c];
+}
+
 } // namespace
 
 int main(int argc, char** argv)
@@ -139,6 +209,7 @@ int main(int argc, char** argv)
     const int device = argc > 1 ? atoi(argv[1]) : 0;
     consumer_side(device);
     producer_side(device);
+    engine_chain(device);
     producer_side_u(device);
     producer_side_f(device);
     printf(dropin_fails ? "DROP-IN CHECK FAILED: %d mismatches\n" : "DROP-IN CHECK PASSED%.0d\n", dropin_fails);
