@@ -203,9 +203,12 @@ def main():
     import torch
 
     rank, local, world = shard.world_from_env()
-    dev = torch.device("cuda", local if world > 1 else 0)
+    # SDRX_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share the cards)
+    backend = os.environ.get("SDRX_BENCH_BACKEND", "nccl")
+    n_dev = max(torch.cuda.device_count(), 1)
+    dev = torch.device("cuda", (local % n_dev if backend == "gloo" else local) if world > 1 else 0)
     torch.cuda.set_device(dev)
-    dist = shard.init_process_group("nccl", rank, world, device=dev) if world > 1 else None   # "nccl" == RCCL on ROCm
+    dist = shard.init_process_group(backend, rank, world, device=dev) if world > 1 else None   # "nccl" == RCCL on ROCm
     n_gpus = world
     my_streams = shard.streams_of_rank(n_gpus, rank, world)       # one stream per GPU: stream s -> GPU s
     assert my_streams == [rank]
@@ -276,7 +279,7 @@ def main():
         step()
     torch.cuda.synchronize(dev)
     h.set_timing(True)
-    elapsed = shard.timed_region(step, args.steps, 0, lambda: torch.cuda.synchronize(dev), dist=dist, device=dev)
+    elapsed = shard.timed_region(step, args.steps, 0, lambda: torch.cuda.synchronize(dev), dist=dist, device=dev if backend != "gloo" else None)
     k_ms, k_n = h.get_timing()
     h.set_timing(False)
 

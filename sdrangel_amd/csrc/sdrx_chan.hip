@@ -48,7 +48,8 @@ static int plan_chain(int32_t in_rate, int32_t req_rate, int32_t req_fc, uint8_t
 namespace {
 
 constexpr int MAX_STAGES = 30;
-constexpr int LDS_BUDGET_DW = 40 * 1024 / 4 - 64;          // four workgroups per CU
+constexpr int LDS_BUDGET_DW_DEFAULT = 40 * 1024 / 4 - 64;  // four workgroups per CU
+static int lds_budget_dw() { const char* e = getenv("SDRX_CHAN_LDS_KB"); return (e && atoi(e) >= 16 && atoi(e) <= 150) ? atoi(e) * 1024 / 4 - 64 : LDS_BUDGET_DW_DEFAULT; }
 constexpr int LDS_HARD_DW = 150 * 1024 / 4;
 
 struct HNode {
@@ -188,7 +189,7 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
         const int h = height(g->trie, root);
         if (h == 0) { g->streams[si].subtree = -1; continue; }
         int levels = 1, nn = 0;
-        while (levels < std::min(h, TK_MAX_LEVELS) && subtree_lds(g->trie, root, levels + 1, &nn) <= LDS_BUDGET_DW) levels++;
+        while (levels < std::min(h, TK_MAX_LEVELS) && subtree_lds(g->trie, root, levels + 1, &nn) <= lds_budget_dw()) levels++;
         int lds_need = subtree_lds(g->trie, root, levels, &nn);
         if (lds_need > LDS_HARD_DW) { set_error("channel tree does not fit LDS"); return SDRX_EINVAL; }
 
