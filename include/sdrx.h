@@ -277,6 +277,23 @@ int sdrx_fdecim_set_timing(sdrx_fdecim_t* h, int enabled);
 int sdrx_fdecim_get_timing(sdrx_fdecim_t* h, double* total_ms, int64_t* launches, int reset);
 int sdrx_fdecim_last_launch(const sdrx_fdecim_t* h, char* kernel_name, int name_cap, int* grid, int* block, int* lds_bytes);
 
+/* ---- DC offset correction of the device stream ----
+ * What DSPDeviceSourceEngine::work does to every FIFO span before the sinks see it when m_dcOffsetCorrection is set
+ * (dspdevicesourceengine.cpp:339-343,375-379 -> iqCorrections(begin, end, false), :175-181,255-259):
+ * re -= (int32) m_iBeta, im -= (int32) m_qBeta with MovingAverageUtil<int32_t,int64_t,1024> averages (total of the last
+ * 1024 samples / 1024, truncating).  State (the last 1023 samples) is carried across calls; reset == fresh engine.
+ * The I/Q imbalance branch (:183-253: float/double averages, a division and a sqrt per sample, serial) is not offered. */
+typedef struct sdrx_dccorr sdrx_dccorr_t;
+int sdrx_dccorr_create(sdrx_dccorr_t** out, int device);
+int sdrx_dccorr_destroy(sdrx_dccorr_t* h);
+int sdrx_dccorr_reset(sdrx_dccorr_t* h);
+/* in place on a host span, like the reference (blocking) */
+int sdrx_dccorr_process(sdrx_dccorr_t* h, int16_t* iq, int64_t n_cplx);
+/* device buffers, asynchronous on the handle's stream; d_out_iq must not alias d_iq */
+int sdrx_dccorr_process_dev(sdrx_dccorr_t* h, const int16_t* d_iq, int16_t* d_out_iq, int64_t n_cplx);
+int sdrx_dccorr_sync(sdrx_dccorr_t* h);
+int sdrx_dccorr_set_stream(sdrx_dccorr_t* h, void* hip_stream);
+
 /* ---- diagnostics ----
  * SURVEY 8(d) quotes the HBM roofline twice: the datasheet's 8 TB/s and what a read-only streaming kernel
  * (sum of int32 over n_bytes, best of reps launches) reaches on this box.  Not part of the sample path. */

@@ -24,6 +24,7 @@
 #include "dsp/decimators.h"
 #include "util/messagequeue.h"
 #include "dsp/samplesinkfifo.h"
+#include "util/movingaverage.h"
 #include "gpudownchannelizerbank.h"
 #define SDRX_HOST_SAMPLE ::Sample      // sdrx::Decimators then takes the reference's SampleVector::iterator*
 #include "sdrx/dsp.hpp"
@@ -161,18 +162,34 @@ void engine_chain(int device)
         refs[c]->handleMessage(cfg); bank.configureChannel(c, rate, fc);
     }
     (void) fsDev;
+    // m_dcOffsetCorrection on: work() corrects each span in place before the sinks see it (:339-343, 375-379).
+    // Reference side: iqCorrections(begin, end, false) on the engine's own MovingAverageUtil members (:175-181, 255-259);
+    // GPU side: sdrx_dccorr_process on the same span.
     struct Drain {
-        static void work(SampleSinkFifo& fifo, std::vector<BasebandSampleSink*>& sinks)
+        MovingAverageUtil<int32_t, int64_t, 1024> m_iBeta, m_qBeta;
+        sdrx_dccorr_t* gpu;
+        Drain() : gpu(0) {}
+        void correct(SampleVector::iterator b, SampleVector::iterator e)
+        {
+            if (gpu) { sdrx_dccorr_process(gpu, reinterpret_cast<int16_t*>(&*b), (int64_t)(e - b)); return; }
+            for (SampleVector::iterator it = b; it < e; it++) {
+                m_iBeta(it->real()); m_qBeta(it->imag());
+                it->m_real -= (int32_t) m_iBeta; it->m_imag -= (int32_t) m_qBeta;
+            }
+        }
+        void work(SampleSinkFifo& fifo, std::vector<BasebandSampleSink*>& sinks)
         {
             while (fifo.fill() > 0) {
                 SampleVector::iterator p1b, p1e, p2b, p2e;
                 const uint count = fifo.readBegin(fifo.fill(), &p1b, &p1e, &p2b, &p2e);
-                if (p1b != p1e) for (size_t i = 0; i < sinks.size(); i++) sinks[i]->feed(p1b, p1e, false);
-                if (p2b != p2e) for (size_t i = 0; i < sinks.size(); i++) sinks[i]->feed(p2b, p2e, false);
+                if (p1b != p1e) { correct(p1b, p1e); for (size_t i = 0; i < sinks.size(); i++) sinks[i]->feed(p1b, p1e, false); }
+                if (p2b != p2e) { correct(p2b, p2e); for (size_t i = 0; i < sinks.size(); i++) sinks[i]->feed(p2b, p2e, false); }
                 fifo.readCommit(count);
             }
         }
     };
+    Drain refDrain, gpuDrain;
+    sdrx_dccorr_create(&gpuDrain.gpu, device);
     std::vector<BasebandSampleSink*> refEngineSinks(refs.begin(), refs.end()), gpuEngineSinks(1, &bank);
     const int block = 2 * 131072;                           // int16 per device callback
     std::vector<qint16> buf((size_t) block);
@@ -180,22 +197,23 @@ void engine_chain(int device)
     long fed = 0;
     for (int b = 0; b < 40; b++) {
         const int len = (b % 5 == 2) ? block - 14 : block;
-        for (int i = 0; i < len; i++) buf[i] = (qint16)((int)(rng() % 4096) - 2048);
+        for (int i = 0; i < len; i++) buf[i] = (qint16)((int)(rng() % 3600) - 1800 + ((i & 1) ? -230 : 170));   // a DC offset to remove
         SampleVector::iterator itR = convR.begin(), itG = convG.begin();
         refDec.decimate8_cen(&itR, buf.data(), len);        // the device thread's callback (limesdrinputthread.cpp:103-135)
         gpuDec.decimate8_cen(&itG, buf.data(), len);
         refFifo.write(convR.begin(), itR);
         gpuFifo.write(convG.begin(), itG);
         fed += itR - convR.begin();
-        if (b % 3 != 1) { Drain::work(refFifo, refEngineSinks); Drain::work(gpuFifo, gpuEngineSinks); }   // sometimes two blocks pile up
+        if (b % 3 != 1) { refDrain.work(refFifo, refEngineSinks); gpuDrain.work(gpuFifo, gpuEngineSinks); }   // sometimes two blocks pile up
     }
-    Drain::work(refFifo, refEngineSinks); Drain::work(gpuFifo, gpuEngineSinks);
+    refDrain.work(refFifo, refEngineSinks); gpuDrain.work(gpuFifo, gpuEngineSinks);
+    sdrx_dccorr_destroy(gpuDrain.gpu);
     for (int c = 0; c < N; c++) {
         char what[96];
         const std::vector<Sample>& a = refSinks[c]->got; const std::vector<Sample>& g = gpuSinks[c]->got;
         bool same = a.size() == g.size() && !a.empty();
         for (size_t i = 0; same && i < a.size(); i++) same = a[i].real() == g[i].real() && a[i].imag() == g[i].imag();
-        snprintf(what, sizeof what, "engine chain: decimate8_cen -> FIFO -> work() -> channel %d", c);
+        snprintf(what, sizeof what, "engine chain: decimate8_cen -> FIFO -> work() + DC corr -> channel %d", c);
         report(what, same, (long) a.size());
     }
     printf("engine chain: %ld samples through the FIFO\n", fed);

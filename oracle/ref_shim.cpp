@@ -255,3 +255,27 @@ void ref_fir_run(void* h, const float* in, int64_t n, float* out)
 }
 
 } // extern "C"
+
+
+// DC offset correction as DSPDeviceSourceEngine::iqCorrections(begin, end, false) runs it (dspdevicesourceengine.cpp:175-181,
+// 255-259) on the reference's own MovingAverageUtil<int32_t, int64_t, 1024> members (dspdevicesourceengine.h:106-107).
+// The engine class itself (a QThread wired to the device and sink registries) is not instantiated; its four lines are.
+#include "util/movingaverage.h"
+namespace { struct DcCorr { MovingAverageUtil<int32_t, int64_t, 1024> m_iBeta, m_qBeta; }; }
+extern "C" {
+void* ref_dccorr_new() { return new DcCorr; }
+void ref_dccorr_free(void* h) { delete static_cast<DcCorr*>(h); }
+void ref_dccorr_process(void* h, const int16_t* iq, int64_t n_cplx, int16_t* out)
+{
+    DcCorr& d = *static_cast<DcCorr*>(h);
+    SampleVector v((size_t) n_cplx);
+    for (int64_t i = 0; i < n_cplx; i++) v[i] = Sample(iq[2*i], iq[2*i+1]);
+    for (SampleVector::iterator it = v.begin(); it < v.end(); it++) {
+        d.m_iBeta(it->real());
+        d.m_qBeta(it->imag());
+        it->m_real -= (int32_t) d.m_iBeta;
+        it->m_imag -= (int32_t) d.m_qBeta;
+    }
+    for (int64_t i = 0; i < n_cplx; i++) { out[2*i] = v[i].real(); out[2*i+1] = v[i].imag(); }
+}
+}

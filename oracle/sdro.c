@@ -281,3 +281,34 @@ int64_t sdro_chain_feed(sdro_chain* c, const int16_t* iq, int64_t n_cplx, int16_
     }
     return n_out;
 }
+
+
+/* ------------------------------------------------------------------ DC offset correction of the device stream
+ * DSPDeviceSourceEngine::iqCorrections(begin, end, imbalanceCorrection = false) (dspdevicesourceengine.cpp:175-181,255-259),
+ * run by work() on every FIFO span before the sinks see it when m_dcOffsetCorrection is set:
+ *     m_iBeta(re); m_qBeta(im);   re -= (int32) m_iBeta;   im -= (int32) m_qBeta;
+ * m_iBeta = MovingAverageUtil<int32_t, int64_t, 1024> (util/movingaverage.h): running total of the last 1024 samples
+ * (fewer while filling up), read back as total / 1024 -- C++ division, truncating, by 1024 even while filling up.
+ * Restated: avg[n] = trunc(sum(x[max(0, n-1023) .. n]) / 1024), y[n] = (int16)(x[n] - avg[n]); state = last 1023 inputs. */
+struct sdro_dccorr { int16_t hist[2][1023]; };
+
+sdro_dccorr* sdro_dccorr_new(void) { return (sdro_dccorr*)calloc(1, sizeof(sdro_dccorr)); }
+void sdro_dccorr_free(sdro_dccorr* d) { free(d); }
+void sdro_dccorr_process(sdro_dccorr* d, const int16_t* iq, int64_t n_cplx, int16_t* out)
+{
+    for (int comp = 0; comp < 2; comp++) {
+        int64_t total = 0;                                  /* the 1023 inputs in front of x[0] (zeros at stream start) */
+        for (int i = 0; i < 1023; i++) total += d->hist[comp][i];
+        for (int64_t n = 0; n < n_cplx; n++) {
+            total += iq[2 * n + comp];                      /* window = the last 1024 inputs including x[n] */
+            out[2 * n + comp] = (int16_t)(iq[2 * n + comp] - (int32_t)(total / 1024));
+            total -= n >= 1023 ? iq[2 * (n - 1023) + comp] : d->hist[comp][n];      /* the oldest one leaves */
+        }
+        int16_t nh[1023];                                   /* new history = last 1023 inputs */
+        for (int i = 0; i < 1023; i++) {
+            const int64_t src = n_cplx - 1023 + i;
+            nh[i] = src >= 0 ? iq[2 * src + comp] : d->hist[comp][i + n_cplx];
+        }
+        memcpy(d->hist[comp], nh, sizeof nh);
+    }
+}

@@ -84,6 +84,13 @@ void    sdro_fir_free(sdro_fir*);
 int32_t sdro_fir_taps(const sdro_fir*, float* out);                      /* ntaps/2 + 1 folded taps */
 void    sdro_fir_run(sdro_fir*, const float* in, int64_t n, float* out); /* streaming: state carried */
 
+/* ---- DC offset correction of the device stream: DSPDeviceSourceEngine::iqCorrections(.., false)
+ * (dspdevicesourceengine.cpp:175-181,255-259; MovingAverageUtil<int32_t,int64_t,1024>) ---- */
+typedef struct sdro_dccorr sdro_dccorr;
+sdro_dccorr* sdro_dccorr_new(void);
+void    sdro_dccorr_free(sdro_dccorr*);
+void    sdro_dccorr_process(sdro_dccorr*, const int16_t* iq, int64_t n_cplx, int16_t* out_iq);
+
 /* ---- float half-band decimators: DecimatorsFI / FF / IF over IntHalfbandFilterEOF<64> (oracle/sdro_fdecim.c) ----
  * in_kind 0: float I/Q, 1: int16 I/Q (DecimatorsIF<qint16,input_bits>); out_kind 0: int16 Sample (FI), 1: float (FF, IF).
  * n_elems = the reference's nbIAndQ; returns #complex outputs (whole groups only, tail dropped). */

@@ -98,6 +98,13 @@ def lib() -> C.CDLL:
         "sdrx_backend_feed_dev": (C.c_int, [vp, vp, vp]),
         "sdrx_backend_feed_bank": (C.c_int, [vp, vp]),
         "sdrx_measure_hbm_read": (C.c_int, [C.c_int, C.c_uint64, C.c_int32, C.POINTER(C.c_double)]),
+        "sdrx_dccorr_create": (C.c_int, [C.POINTER(vp), C.c_int]),
+        "sdrx_dccorr_destroy": (C.c_int, [vp]),
+        "sdrx_dccorr_reset": (C.c_int, [vp]),
+        "sdrx_dccorr_process": (C.c_int, [vp, vp, C.c_int64]),
+        "sdrx_dccorr_process_dev": (C.c_int, [vp, vp, vp, C.c_int64]),
+        "sdrx_dccorr_sync": (C.c_int, [vp]),
+        "sdrx_dccorr_set_stream": (C.c_int, [vp, vp]),
         "sdrx_fdecim_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
         "sdrx_fdecim_destroy": (C.c_int, [vp]),
         "sdrx_fdecim_reset": (C.c_int, [vp]),
@@ -297,6 +304,39 @@ class FloatDecimators:
         g, b, l = C.c_int(), C.c_int(), C.c_int()
         _check(lib().sdrx_fdecim_last_launch(self._h, name, 128, C.byref(g), C.byref(b), C.byref(l)), "last_launch")
         return {"kernel": name.value.decode(), "grid": g.value, "block": b.value, "lds_bytes": l.value}
+
+
+class DcCorrection:
+    """DSPDeviceSourceEngine::iqCorrections(begin, end, false): the DC offset correction of the device stream"""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        _check(lib().sdrx_dccorr_create(C.byref(self._h), device), "sdrx_dccorr_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sdrx_dccorr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def reset(self):
+        _check(lib().sdrx_dccorr_reset(self._h), "sdrx_dccorr_reset")
+
+    def process(self, iq) -> np.ndarray:
+        """returns the corrected copy of an int16 I/Q span (the C call works in place)"""
+        buf = np.array(iq, dtype=np.int16, copy=True)
+        _check(lib().sdrx_dccorr_process(self._h, buf.ctypes.data, buf.size // 2), "sdrx_dccorr_process")
+        return buf
+
+    def process_dev(self, d_in_ptr: int, d_out_ptr: int, n_cplx: int):
+        _check(lib().sdrx_dccorr_process_dev(self._h, d_in_ptr, d_out_ptr, n_cplx), "sdrx_dccorr_process_dev")
+
+    def sync(self):
+        _check(lib().sdrx_dccorr_sync(self._h), "sdrx_dccorr_sync")
+
+    def set_stream(self, hip_stream: int | None):
+        _check(lib().sdrx_dccorr_set_stream(self._h, hip_stream), "sdrx_dccorr_set_stream")
 
 
 def chan_plan(in_rate: int, req_rate: int, req_fc: int):

@@ -218,3 +218,24 @@ def synth_iq(n_cplx, seed=1, amp=2047, tone=None):
         x[0::2] += np.round(a * np.cos(2 * np.pi * f * t)).astype(np.int64)
         x[1::2] += np.round(a * np.sin(2 * np.pi * f * t)).astype(np.int64)
     return np.clip(x, -32768, 32767).astype(np.int16)
+
+
+class DcCorr:
+    """oracle DC offset correction (DSPDeviceSourceEngine::iqCorrections, DC only), streaming"""
+
+    def __init__(self):
+        self.L = lib()
+        self.L.sdro_dccorr_new.restype = C.c_void_p
+        self.L.sdro_dccorr_free.argtypes = [C.c_void_p]
+        self.L.sdro_dccorr_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        self.h = self.L.sdro_dccorr_new()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.sdro_dccorr_free(self.h); self.h = None
+
+    def process(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.int16)
+        out = np.empty_like(iq)
+        self.L.sdro_dccorr_process(self.h, iq.ctypes.data, iq.size // 2, out.ctypes.data)
+        return out

@@ -26,5 +26,5 @@ def test_reference_objects_and_gpu_adapter_agree_in_one_process():
     assert out.returncode == 0, (out.returncode, out.stdout[-3000:], out.stderr[-2000:])
     assert "DROP-IN CHECK PASSED" in out.stdout
     assert out.stdout.count(" OK ") >= 12 * 2 + 12 + 6, out.stdout
-    assert out.stdout.count("engine chain: decimate8_cen -> FIFO -> work() -> channel") == 6
+    assert out.stdout.count("engine chain: decimate8_cen -> FIFO -> work() + DC corr -> channel") == 6
     assert "MISMATCH" not in out.stdout

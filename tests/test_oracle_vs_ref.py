@@ -178,3 +178,19 @@ def test_fftfilt_run_asym_vestigial_sideband():
                 nb = R.ref_fftfilt_run(hr, mode, seg.ctypes.data, b - a, yb.ctypes.data)
                 assert na == nb and np.array_equal(ya.view(np.uint32), yb.view(np.uint32)), (mode, fopp, fin, a, b)
             O.sdro_fftfilt_free(ho); R.ref_fftfilt_free(hr)
+
+
+def test_dc_offset_correction_vs_moving_average_util():
+    """oracle DC correction vs the reference's MovingAverageUtil<int32_t,int64_t,1024> driven as iqCorrections(.., false) does"""
+    R = C.CDLL(REF)
+    R.ref_dccorr_new.restype = C.c_void_p
+    R.ref_dccorr_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    R.ref_dccorr_free.argtypes = [C.c_void_p]
+    h = R.ref_dccorr_new(); o = orc.DcCorr()
+    rng = np.random.default_rng(2)
+    for n in (5, 1000, 1023, 1024, 1, 3000, 70000, 0, 2047):
+        x = (rng.integers(-30000, 30000, 2 * n) + 1500).clip(-32768, 32767).astype(np.int16)
+        want = np.zeros(2 * n + 2, np.int16)
+        R.ref_dccorr_process(h, x.ctypes.data, n, want.ctypes.data)
+        assert np.array_equal(o.process(x), want[: 2 * n]), n
+    R.ref_dccorr_free(h)
