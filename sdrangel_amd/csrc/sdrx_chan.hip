@@ -49,7 +49,15 @@ namespace {
 
 constexpr int MAX_STAGES = 30;
 constexpr int LDS_BUDGET_DW_DEFAULT = 40 * 1024 / 4 - 64;  // four workgroups per CU
-static int lds_budget_dw() { const char* e = getenv("SDRX_CHAN_LDS_KB"); return (e && atoi(e) >= 16 && atoi(e) <= 150) ? atoi(e) * 1024 / 4 - 64 : LDS_BUDGET_DW_DEFAULT; }
+// Wide banks (cfg 4: 256 channels) have a dense tree top whose levels need ~25 KB each; with 40 KB the greedy cut ends up
+// with 1-2 levels per pass and six passes.  64 KB (two workgroups per CU) measured 1.29 vs 1.42 ms per 64 Mi-sample feed
+// for 256 channels, but 0.82 vs 0.71 ms for 128 and 0.62 vs 0.45 ms for 32 -- so only wide banks get it.
+static int lds_budget_dw(size_t n_channels)
+{
+    const char* e = getenv("SDRX_CHAN_LDS_KB");
+    if (e && atoi(e) >= 16 && atoi(e) <= 150) return atoi(e) * 1024 / 4 - 64;
+    return n_channels >= 192 ? 64 * 1024 / 4 - 64 : LDS_BUDGET_DW_DEFAULT;
+}
 constexpr int LDS_HARD_DW = 150 * 1024 / 4;
 
 struct HNode {
@@ -189,7 +197,7 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
         const int h = height(g->trie, root);
         if (h == 0) { g->streams[si].subtree = -1; continue; }
         int levels = 1, nn = 0;
-        while (levels < std::min(h, TK_MAX_LEVELS) && subtree_lds(g->trie, root, levels + 1, &nn) <= lds_budget_dw()) levels++;
+        while (levels < std::min(h, TK_MAX_LEVELS) && subtree_lds(g->trie, root, levels + 1, &nn) <= lds_budget_dw(g->chans.size())) levels++;
         int lds_need = subtree_lds(g->trie, root, levels, &nn);
         if (lds_need > LDS_HARD_DW) { set_error("channel tree does not fit LDS"); return SDRX_EINVAL; }
 
