@@ -48,7 +48,7 @@ static int plan_chain(int32_t in_rate, int32_t req_rate, int32_t req_fc, uint8_t
 namespace {
 
 constexpr int MAX_STAGES = 30;
-constexpr int LDS_BUDGET_DW_DEFAULT = 40 * 1024 / 4 - 64;  // four workgroups per CU
+constexpr int LDS_BUDGET_DW_DEFAULT = 40 * 1024 / 4 - 64;  // four workgroups per CU (the 64 spare dwords hold the kernel's static copy of TkSubtree)
 // Wide banks (cfg 4: 256 channels) have a dense tree top whose levels need ~25 KB each; with 40 KB the greedy cut ends up
 // with 1-2 levels per pass and six passes.  64 KB (two workgroups per CU) measured 1.29 vs 1.42 ms per 64 Mi-sample feed
 // for 256 channels, but 0.82 vs 0.71 ms for 128 and 0.62 vs 0.45 ms for 32 -- so only wide banks get it.
@@ -58,7 +58,7 @@ static int lds_budget_dw(size_t n_channels)
     if (e && atoi(e) >= 16 && atoi(e) <= 150) return atoi(e) * 1024 / 4 - 64;
     return n_channels >= 192 ? 64 * 1024 / 4 - 64 : LDS_BUDGET_DW_DEFAULT;
 }
-constexpr int LDS_HARD_DW = 150 * 1024 / 4;
+constexpr int LDS_HARD_DW = 150 * 1024 / 4;             // < the 159 KB of dynamic LDS the kernel may ask for
 
 struct HNode {
     int parent = -1, mode = 0, depth = 0;
@@ -130,7 +130,7 @@ int subtree_lds(const std::vector<HNode>& trie, int root, int levels, int* n_nod
         if (cur.empty()) break;
     }
     *n_nodes_out = n_entries;
-    return region[0] + region[1] + n_arrays * 16 + n_entries * TK_NODE_DW;
+    return region[0] + region[1] + n_arrays * 16 + n_entries * TK_NODE_DW + n_arrays;      // + one table dword per array
 }
 
 int height(const std::vector<HNode>& trie, int id)
@@ -236,8 +236,7 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
             TkLevel& lv = st.lv[rel - 1];
             lv.node_base = rel_nodes;
             lv.nout = TK_CHUNK >> rel;
-            int jl = 0; while ((8 << jl) < lv.nout) jl++;
-            lv.jobs_log2 = jl;
+            lv.r_log2 = 3; lv.jobs_log2 = 0;                           // fixed up below once the level's entry count is known
             lv.arr_base = (int)g->arrays.size() - st.array_base;
             int n_entries = 0;
             for (size_t pi = 0; pi < cur.size(); pi++) {
@@ -302,6 +301,14 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
             rel_nodes += n_entries;
             lv.arr_cnt = (int)g->arrays.size() - st.array_base - lv.arr_base;
             lv.n_nodes = n_entries;
+            {   // outputs per job: 8 while that gives every lane of the workgroup a job, else 4, else 2 (a level costs one job time)
+                int rl = 3;
+                const char* er = getenv("SDRX_CHAN_R8");
+                if (!er) while (rl > 1 && (long)n_entries * (lv.nout >> rl) < TK_THREADS) rl--;
+                lv.r_log2 = rl;
+                int jl = 0; while (((1 << rl) << jl) < lv.nout) jl++;
+                lv.jobs_log2 = jl;
+            }
             cur.swap(nxt); cur_arms.swap(nxt_arms);
         }
         st.n_nodes = rel_nodes;
@@ -325,7 +332,10 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
             }
         }
         st.node_tab = store_base + 16 * st.n_arrays;
-        st.lds_dwords = st.node_tab + rel_nodes * TK_NODE_DW;
+        st.arr_tab = st.node_tab + rel_nodes * TK_NODE_DW;
+        st.lds_dwords = st.arr_tab + st.n_arrays;
+        if (st.lds_dwords > 0xffff) { set_error("channel tree does not fit the 16-bit LDS offsets of the array table"); return SDRX_EINVAL; }
+        for (int l = 0; l < levels; l++) st.lv[l].in_len = arm_len(l);
         g->max_lds_dw = std::max(g->max_lds_dw, st.lds_dwords);
         g->streams[si].subtree = (int)g->subtrees.size();
         g->subtrees.push_back(st);

@@ -50,9 +50,10 @@ struct TkNode {                 // 32 dwords
 static_assert(sizeof(TkOut) == 48 && sizeof(TkNode) == TK_NODE_DW * 4, "node table layout");
 
 struct TkLevel {
-    int node_base, n_nodes, jobs_log2, nout;     // nout = outputs per node per chunk
+    int node_base, n_nodes, jobs_log2, nout;     // nout = outputs per node per chunk; jobs per node = nout >> r_log2
     int arr_base, arr_cnt;                       // arrays PRODUCED by this level's stages (relative to the subtree's array list)
-    int pad[2];
+    int r_log2;                                  // outputs per job: 8, 4 or 2
+    int in_len;                                  // dwords of every array this level READS (its parents' arms)
 };
 
 struct TkSubtree {
@@ -63,6 +64,7 @@ struct TkSubtree {
     int root_arr_cnt;           // the first root_arr_cnt arrays are the root arms
     int lds_dwords;             // two arm regions + history store + node table copy
     int node_tab;               // LDS dword offset of the node table copy
+    int arr_tab;                // LDS dword offset of the array table copy: off | store << 16, one dword per array
     int rootE_I, rootE_Q, rootO_I, rootO_Q, rootA_I, rootA_Q;   // root arms (-1: none)
     TkLevel lv[TK_MAX_LEVELS];
 };
@@ -108,14 +110,22 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
     const long first = sp.c_first + (long)blockIdx.x * sp.cps;
     if (first > sp.c_last) return;
     long last = first + sp.cps - 1; if (last > sp.c_last) last = sp.c_last;
+    // The per-array table the level loop walks three times per level and chunk is copied into LDS once per workgroup, one
+    // dword per array (window offset | history slot << 16): read from global memory each walk is a dependent ~1 us round trip.
+    // (The subtree descriptor stays in global/constant memory: the compiler keeps its fields in SGPRs; an LDS copy of it
+    // turned every `st.` access into an LDS load and tripled the kernel time.)
     const TkSubtree& st = subtrees[sp.subtree];
     const int tid = threadIdx.x;
 
     for (int i = tid; i < st.lds_dwords; i += NT) lds[i] = 0;
     __syncthreads();
-    {   // node table -> LDS
+    {   // node table and array table -> LDS
         const uint32_t* src = reinterpret_cast<const uint32_t*>(nodes + st.node_base);
         for (int i = tid; i < st.n_nodes * TK_NODE_DW; i += NT) lds[st.node_tab + i] = src[i];
+        for (int i = tid; i < st.n_arrays; i += NT) {
+            const TkArray a = arrays[st.array_base + i];
+            lds[st.arr_tab + i] = (uint32_t)a.off | ((uint32_t)a.store << 16);
+        }
     }
 
     uint4 pre[LPT];
@@ -157,8 +167,8 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
             }
         }
         for (int i = tid; i < st.root_arr_cnt * 16; i += NT) {                 // history in front of the root windows
-            const TkArray a = arrays[st.array_base + (i >> 4)];
-            lds[a.off + (i & 15)] = lds[a.store + (i & 15)];
+            const uint32_t a = lds[st.arr_tab + (i >> 4)];
+            lds[(a & 0xffffu) + (i & 15)] = lds[(a >> 16) + (i & 15)];
         }
         if (chunk < last) fetch(chunk + 1);
         __syncthreads();
@@ -168,36 +178,59 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
             const TkLevel lv = st.lv[l];
             const int njobs = lv.n_nodes << lv.jobs_log2;
             for (int i = tid; i < lv.arr_cnt * 16; i += NT) {                      // history of the arrays this level produces
-                const TkArray a = arrays[st.array_base + lv.arr_base + (i >> 4)];
-                lds[a.off + (i & 15)] = lds[a.store + (i & 15)];
+                const uint32_t a = lds[st.arr_tab + lv.arr_base + (i >> 4)];
+                lds[(a & 0xffffu) + (i & 15)] = lds[(a >> 16) + (i & 15)];
             }
-            for (int j = tid; j < njobs; j += NT) {
+            // One job = (table entry, R consecutive outputs).  R = 8 while that still gives every lane a job; narrow levels
+            // (few entries, short chunks: the bottom of every subtree) drop to R = 4 or 2 so that the lanes stay busy --
+            // a level costs one job time, and a job's time is proportional to R.
+            auto job = [&](auto Rc, const int j) {
+                constexpr int R = decltype(Rc)::value;
+                constexpr int NW = (R + 32) / 2;                                   // window dwords: int16 i holds o[k0 - 32 + i]
+                constexpr int NE = R / 2 + 1;
                 const int ni = lv.node_base + (j >> lv.jobs_log2);
                 const int t = j & ((1 << lv.jobs_log2) - 1);
                 const uint4* nt = reinterpret_cast<const uint4*>(lds + st.node_tab + ni * TK_NODE_DW);
                 const uint4 n0 = nt[0];
-                // --- shared part: 8 outputs x (I,Q) of the 24-tap odd-arm sum, packed int16 arms
-                int sI[8], sQ[8];
-                uint32_t vI[5], vQ[5];
+                // --- shared part: R outputs x (I,Q) of the 24-tap odd-arm sum, packed int16 arms
+                int sI[R], sQ[R];
+                uint32_t vI[NE], vQ[NE];
                 {
-                    const uint32_t* oI = lds + (int)n0.x, *oQ = lds + (int)n0.y;
-                    const uint32_t* cI = lds + (int)n0.z, *cQ = lds + (int)n0.w;
-                    uint32_t wI[20], wQ[20];
-                    const uint4* pI = reinterpret_cast<const uint4*>(oI + 4 * t);
-                    const uint4* pQ = reinterpret_cast<const uint4*>(oQ + 4 * t);
-#pragma unroll
-                    for (int q = 0; q < 5; q++) {
-                        uint4 a = pI[q], b = pQ[q];
-                        wI[4*q] = a.x; wI[4*q+1] = a.y; wI[4*q+2] = a.z; wI[4*q+3] = a.w;
-                        wQ[4*q] = b.x; wQ[4*q+1] = b.y; wQ[4*q+2] = b.z; wQ[4*q+3] = b.w;
-                    }
+                    const uint32_t* oI = lds + (int)n0.x + (R / 2) * t, *oQ = lds + (int)n0.y + (R / 2) * t;
+                    const uint32_t* cI = lds + (int)n0.z + (R / 2) * t, *cQ = lds + (int)n0.w + (R / 2) * t;
+                    uint32_t wI[NW], wQ[NW];
                     constexpr int EB = (32 - (hb_pairs<48>() - 1) - 1) / 2;      // 10
-                    ld_centre5<EB>(cI + 4 * t, vI);
-                    ld_centre5<EB>(cQ + 4 * t, vQ);
-                    static_for<0, 8>([&](auto rc) {
+                    if constexpr (R == 8) {
+                        const uint4* pI = reinterpret_cast<const uint4*>(oI);
+                        const uint4* pQ = reinterpret_cast<const uint4*>(oQ);
+#pragma unroll
+                        for (int q = 0; q < 5; q++) {
+                            uint4 a = pI[q], b = pQ[q];
+                            wI[4*q] = a.x; wI[4*q+1] = a.y; wI[4*q+2] = a.z; wI[4*q+3] = a.w;
+                            wQ[4*q] = b.x; wQ[4*q+1] = b.y; wQ[4*q+2] = b.z; wQ[4*q+3] = b.w;
+                        }
+                        ld_centre5<EB>(cI, vI);
+                        ld_centre5<EB>(cQ, vQ);
+                    } else if constexpr (R == 4) {
+                        const uint2* pI = reinterpret_cast<const uint2*>(oI);
+                        const uint2* pQ = reinterpret_cast<const uint2*>(oQ);
+#pragma unroll
+                        for (int q = 0; q < NW / 2; q++) {
+                            uint2 a = pI[q], b = pQ[q];
+                            wI[2*q] = a.x; wI[2*q+1] = a.y; wQ[2*q] = b.x; wQ[2*q+1] = b.y;
+                        }
+                        const uint2 a = *reinterpret_cast<const uint2*>(cI + EB), b = *reinterpret_cast<const uint2*>(cQ + EB);
+                        vI[0] = a.x; vI[1] = a.y; vI[2] = cI[EB + 2]; vQ[0] = b.x; vQ[1] = b.y; vQ[2] = cQ[EB + 2];
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < NW; q++) { wI[q] = oI[q]; wQ[q] = oQ[q]; }
+#pragma unroll
+                        for (int q = 0; q < NE; q++) { vI[q] = cI[EB + q]; vQ[q] = cQ[EB + q]; }
+                    }
+                    static_for<0, R>([&](auto rc) {
                         constexpr int r = decltype(rc)::value;
                         int aI = 0, aQ = 0;
-                        static_for<0, 20>([&](auto dc) {
+                        static_for<0, NW>([&](auto dc) {
                             constexpr int d = decltype(dc)::value;
                             constexpr uint32_t cf = pk_coef<48, MODE_CEN>(r, d);
                             if constexpr (cf != 0) { aI = dot2(wI[d], cf, aI); aQ = dot2(wQ[d], cf, aQ); }
@@ -205,11 +238,11 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                         sI[r] = aI; sQ[r] = aQ;
                     });
                 }
-                const long abs0 = chunk * lv.nout + 8 * t;
+                const long abs0 = chunk * lv.nout + R * t;
                 // --- per stage of the entry: centre tap, int16 store, own arms, sinks
                 auto emit = [&](const uint4 o0, const uint4 o1, const uint4 oc) {
-                    int yI[8], yQ[8];
-                    static_for<0, 8>([&](auto rc) {
+                    int yI[R], yQ[R];
+                    static_for<0, R>([&](auto rc) {
                         constexpr int r = decltype(rc)::value;
                         constexpr int dd = (r + 1) >> 1;
                         const int aI = dot2(vI[dd], (r & 1) ? oc.y : oc.x, sI[r]);
@@ -217,22 +250,45 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                         yI[r] = (int)(int16_t)(aI >> (HB_SHIFT - 1));               // Sample::setReal (:828)
                         yQ[r] = (int)(int16_t)(aQ >> (HB_SHIFT - 1));
                     });
+                    auto alt = [](uint32_t v) { return ((0u - v) & 0xffffu) | (v & 0xffff0000u); };   // arm entry m even (low half): wrap-negated
                     if ((int)o0.x >= 0) {                                          // own arms for the children
-                        const int p = HIST / 2 + 2 * t;
-                        const uint32_t e0I = pack_iq(yI[0], yI[2]), e1I = pack_iq(yI[4], yI[6]);
-                        const uint32_t e0Q = pack_iq(yQ[0], yQ[2]), e1Q = pack_iq(yQ[4], yQ[6]);
-                        *reinterpret_cast<uint2*>(lds + (int)o0.x + p) = make_uint2(e0I, e1I);
-                        *reinterpret_cast<uint2*>(lds + (int)o0.y + p) = make_uint2(e0Q, e1Q);
-                        const uint32_t o0I = pack_iq(yI[1], yI[3]), o1I = pack_iq(yI[5], yI[7]);
-                        const uint32_t o0Q = pack_iq(yQ[1], yQ[3]), o1Q = pack_iq(yQ[5], yQ[7]);
-                        if ((int)o0.z >= 0) {
-                            *reinterpret_cast<uint2*>(lds + (int)o0.z + p) = make_uint2(o0I, o1I);
-                            *reinterpret_cast<uint2*>(lds + (int)o0.w + p) = make_uint2(o0Q, o1Q);
-                        }
-                        if ((int)o1.x >= 0) {
-                            auto alt = [](uint32_t v) { return ((0u - v) & 0xffffu) | (v & 0xffff0000u); };
-                            *reinterpret_cast<uint2*>(lds + (int)o1.x + p) = make_uint2(alt(o0I), alt(o1I));
-                            *reinterpret_cast<uint2*>(lds + (int)o1.y + p) = make_uint2(alt(o0Q), alt(o1Q));
+                        if constexpr (R == 8) {
+                            const int p = HIST / 2 + 2 * t;
+                            const uint32_t e0I = pack_iq(yI[0], yI[2]), e1I = pack_iq(yI[4], yI[6]);
+                            const uint32_t e0Q = pack_iq(yQ[0], yQ[2]), e1Q = pack_iq(yQ[4], yQ[6]);
+                            *reinterpret_cast<uint2*>(lds + (int)o0.x + p) = make_uint2(e0I, e1I);
+                            *reinterpret_cast<uint2*>(lds + (int)o0.y + p) = make_uint2(e0Q, e1Q);
+                            const uint32_t o0I = pack_iq(yI[1], yI[3]), o1I = pack_iq(yI[5], yI[7]);
+                            const uint32_t o0Q = pack_iq(yQ[1], yQ[3]), o1Q = pack_iq(yQ[5], yQ[7]);
+                            if ((int)o0.z >= 0) {
+                                *reinterpret_cast<uint2*>(lds + (int)o0.z + p) = make_uint2(o0I, o1I);
+                                *reinterpret_cast<uint2*>(lds + (int)o0.w + p) = make_uint2(o0Q, o1Q);
+                            }
+                            if ((int)o1.x >= 0) {
+                                *reinterpret_cast<uint2*>(lds + (int)o1.x + p) = make_uint2(alt(o0I), alt(o1I));
+                                *reinterpret_cast<uint2*>(lds + (int)o1.y + p) = make_uint2(alt(o0Q), alt(o1Q));
+                            }
+                        } else if constexpr (R == 4) {
+                            const int p = HIST / 2 + t;
+                            lds[(int)o0.x + p] = pack_iq(yI[0], yI[2]);
+                            lds[(int)o0.y + p] = pack_iq(yQ[0], yQ[2]);
+                            const uint32_t oI1 = pack_iq(yI[1], yI[3]), oQ1 = pack_iq(yQ[1], yQ[3]);
+                            if ((int)o0.z >= 0) { lds[(int)o0.z + p] = oI1; lds[(int)o0.w + p] = oQ1; }
+                            if ((int)o1.x >= 0) { lds[(int)o1.x + p] = alt(oI1); lds[(int)o1.y + p] = alt(oQ1); }
+                        } else {
+                            // outputs 2t (even -> E'[t]) and 2t + 1 (odd -> O'[t]): one int16 per arm
+                            const int h = HIST + t;                                // int16 index inside the array
+                            reinterpret_cast<uint16_t*>(lds + (int)o0.x)[h] = (uint16_t)yI[0];
+                            reinterpret_cast<uint16_t*>(lds + (int)o0.y)[h] = (uint16_t)yQ[0];
+                            if ((int)o0.z >= 0) {
+                                reinterpret_cast<uint16_t*>(lds + (int)o0.z)[h] = (uint16_t)yI[1];
+                                reinterpret_cast<uint16_t*>(lds + (int)o0.w)[h] = (uint16_t)yQ[1];
+                            }
+                            if ((int)o1.x >= 0) {
+                                const bool neg = (t & 1) == 0;                    // entry m = t even: wrap-negated
+                                reinterpret_cast<uint16_t*>(lds + (int)o1.x)[h] = (uint16_t)(neg ? 0 - yI[1] : yI[1]);
+                                reinterpret_cast<uint16_t*>(lds + (int)o1.y)[h] = (uint16_t)(neg ? 0 - yQ[1] : yQ[1]);
+                            }
                         }
                     }
                     if (live) {                                                    // channel ends / node streams
@@ -240,14 +296,14 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                             const TkSink sk = sinks[si];
                             const long rel = abs0 - sk.lo, span = sk.hi - sk.lo;
                             uint32_t* dst = sk.ptr + (abs0 - sk.base);
-                            if (rel >= 0 && rel + 8 <= span) {                     // whole job in range: no per-sample guards
+                            if (rel >= 0 && rel + R <= span) {                     // whole job in range: no per-sample guards
 #pragma unroll
-                                for (int r = 0; r < 8; r++)
+                                for (int r = 0; r < R; r++)
                                     dst[r] = sk.shift ? pack_iq(div_pow2_trunc(yI[r], sk.shift), div_pow2_trunc(yQ[r], sk.shift))
                                                       : pack_iq(yI[r], yQ[r]);
-                            } else if (rel > -8 && rel < span) {
+                            } else if (rel > -R && rel < span) {
 #pragma unroll
-                                for (int r = 0; r < 8; r++)
+                                for (int r = 0; r < R; r++)
                                     if (rel + r >= 0 && rel + r < span)
                                         dst[r] = sk.shift ? pack_iq(div_pow2_trunc(yI[r], sk.shift), div_pow2_trunc(yQ[r], sk.shift))
                                                           : pack_iq(yI[r], yQ[r]);
@@ -258,12 +314,15 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                 };
                 emit(nt[1], nt[2], nt[3]);
                 if ((int)nt[5].w != 0) emit(nt[4], nt[5], nt[6]);                  // fused upper sibling
-            }
+            };
+            if (lv.r_log2 == 3)      for (int j = tid; j < njobs; j += NT) job(std::integral_constant<int, 8>{}, j);
+            else if (lv.r_log2 == 2) for (int j = tid; j < njobs; j += NT) job(std::integral_constant<int, 4>{}, j);
+            else                     for (int j = tid; j < njobs; j += NT) job(std::integral_constant<int, 2>{}, j);
             {   // the arrays this level READ are complete and still intact: keep their last 16 dwords for the next chunk
                 const int sb = l == 0 ? 0 : st.lv[l - 1].arr_base, sc = l == 0 ? st.root_arr_cnt : st.lv[l - 1].arr_cnt;
                 for (int i = tid; i < sc * 16; i += NT) {
-                    const TkArray a = arrays[st.array_base + sb + (i >> 4)];
-                    lds[a.store + (i & 15)] = lds[a.off + a.len - 16 + (i & 15)];
+                    const uint32_t a = lds[st.arr_tab + sb + (i >> 4)];
+                    lds[(a >> 16) + (i & 15)] = lds[(a & 0xffffu) + lv.in_len - 16 + (i & 15)];
                 }
             }
             __syncthreads();
