@@ -192,7 +192,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="decim64", choices=["decim64", "chan32", "chan128", "cfg4", "fi64"])
-    ap.add_argument("--batch", type=int, default=256 * 1024 * 1024, help="complex samples per step per GPU (1 GiB of int16 I/Q)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="complex samples per step per GPU; default per workload: decim64 1 Gi (4 GiB of int16 I/Q), chan32/chan128 256 Mi, "
+                         "cfg4 64 Mi, fi64 512 Mi (4 GiB of float I/Q).  One wave of the decimator lives ~0.3 ms, so short launches lose a "
+                         "large part of their time to the tail: 256 Mi samples run at 385 GS/s, 1 Gi at 494 GS/s (DESIGN.md 6)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary cfg-3 (32-channel bank) measurement")
     args = ap.parse_args()
@@ -213,11 +216,11 @@ def main():
     my_streams = shard.streams_of_rank(n_gpus, rank, world)       # one stream per GPU: stream s -> GPU s
     assert my_streams == [rank]
 
-    B = args.batch
+    B = args.batch if args.batch else {"decim64": 1 << 30, "chan32": 1 << 28, "chan128": 1 << 28, "cfg4": 1 << 26, "fi64": 1 << 29}[args.workload]
     g = torch.Generator(device=dev); g.manual_seed(5489 + rank)
     # sdrbench-shaped data: uniform 12-bit noise, I/Q interleaved (mainbench.cpp:76-79) + an in-band tone
     x = torch.randint(-2048, 2048, (2 * B,), generator=g, device=dev, dtype=torch.int32)
-    t = torch.arange(B, device=dev, dtype=torch.float32)
+    t = torch.arange(B, device=dev, dtype=torch.int32).remainder_(10000).to(torch.float32)    # 0.0011 * 10000 = 11 whole cycles: exact at any B
     x[0::2] += (600 * torch.cos(2 * torch.pi * 0.0011 * t)).to(torch.int32)
     x[1::2] += (600 * torch.sin(2 * torch.pi * 0.0011 * t)).to(torch.int32)
     x = x.clamp_(-32768, 32767).to(torch.int16)
@@ -226,7 +229,6 @@ def main():
 
     if args.workload == "fi64":
         # DecimatorsFI::decimate64_cen (AirspyHF thread), float I/Q in, int16 Samples out
-        B = min(B, 128 * 1024 * 1024)
         xf = (x[: 2 * B].to(torch.float32) / 4096.0).contiguous()
         del x
         x = xf
@@ -303,7 +305,7 @@ def main():
         }
         if n_gpus == 1 and args.workload == "decim64" and not args.no_also:
             # the other half of the metric's name: BASELINE configs[2], 32-channel DownChannelizer bank, same GPU, same run
-            nb = 64 * 1024 * 1024
+            nb = min(B, 256 * 1024 * 1024)
             k32 = torch.arange(32, dtype=torch.float64)
             fcs32 = (-15_000_000 + k32 * (30_000_000 / 31) + 137 * k32).to(torch.int64).tolist()
             bank = sa.ChannelizerBank(61_440_000, [48000] * 32, fcs32, device=dev.index)

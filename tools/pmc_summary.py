@@ -23,7 +23,7 @@ def fold(pattern):
 
 
 out = {"note": "bytes per launch; read = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB; separate --pmc passes", "kernels": []}
-for wl, batch, alg in (("decim64", b_decim, 4.0625), ("chan32", b_chan, 4.125), ("fi64", 134217728, 8.0625)):
+for wl, batch, alg in (("decim64", b_decim, 4.0625), ("chan32", b_chan, 4.125), ("fi64", 536870912, 8.0625)):
     f = fold(f"pmc_fetch_{wl}"); w = fold(f"pmc_write_{wl}")
     kernels = sorted({k for k, _ in list(f) + list(w)})
     for k in kernels:

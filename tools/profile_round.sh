@@ -8,13 +8,13 @@ export TMPDIR=/tmp
 set -x
 timeout -k 10 600 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 timeout -k 10 300 python bench.py > $O/bench_decim64.json 2> $O/bench_decim64.err; cat $O/bench_decim64.json
-timeout -k 10 300 python bench.py --workload chan32 --steps 5 --batch 67108864 --no-cpu > $O/bench_chan32.json 2> $O/bench_chan32.err; cat $O/bench_chan32.json
+timeout -k 10 300 python bench.py --workload chan32 --steps 5 --no-cpu > $O/bench_chan32.json 2> $O/bench_chan32.err; cat $O/bench_chan32.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_decim64 -- python3 bench.py --no-cpu --steps 10 > $O/trace_decim64.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_chan32 -- python3 bench.py --workload chan32 --batch 67108864 --no-cpu --steps 5 > $O/trace_chan32.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_chan32 -- python3 bench.py --workload chan32 --no-cpu --steps 5 > $O/trace_chan32.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_decim64 -- python3 bench.py --no-cpu --steps 3 --warmup 1 > $O/pmc_fetch_decim64.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_decim64 -- python3 bench.py --no-cpu --steps 3 --warmup 1 > $O/pmc_write_decim64.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_chan32 -- python3 bench.py --workload chan32 --batch 67108864 --no-cpu --steps 3 --warmup 1 > $O/pmc_fetch_chan32.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_chan32 -- python3 bench.py --workload chan32 --batch 67108864 --no-cpu --steps 3 --warmup 1 > $O/pmc_write_chan32.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_chan32 -- python3 bench.py --workload chan32 --no-cpu --steps 3 --warmup 1 > $O/pmc_fetch_chan32.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_chan32 -- python3 bench.py --workload chan32 --no-cpu --steps 3 --warmup 1 > $O/pmc_write_chan32.log 2>&1
 # cfg 4 (256 channels + demod front) and the float decimators
 timeout -k 10 300 python bench.py --workload cfg4 --batch 67108864 --steps 5 --no-cpu > $O/bench_cfg4.json 2> $O/bench_cfg4.err; cat $O/bench_cfg4.json
 timeout -k 10 300 python bench.py --workload fi64 > $O/bench_fi64.json 2> $O/bench_fi64.err; cat $O/bench_fi64.json
