@@ -21,8 +21,9 @@ def _dev_noise(n_cplx, seed, amp=2047):
 
 
 def test_decim64_bench_batch_bit_exact_and_split_invariant():
-    """cfg 2 at the bench's own batch: 256 Mi samples (1 GiB) resident, decimate64_cen"""
-    n = 256 * 1024 * 1024
+    """cfg 2 at the bench's own batch: 1 Gi samples (4 GiB) resident, decimate64_cen -- the launch size at which the library
+    switches to 64 sub-chunks per segment"""
+    n = 1024 * 1024 * 1024
     x = _dev_noise(n, 5489)
     out = torch.empty(2 * (n >> 6) + 64, dtype=torch.int16, device="cuda")
     g = sa.Decimators(6, sa.FC_CEN, 12)
@@ -31,12 +32,15 @@ def test_decim64_bench_batch_bit_exact_and_split_invariant():
     torch.cuda.synchronize()
     assert n_out == n >> 6
     whole = out[: 2 * n_out].cpu().numpy().copy()
-    # the reference's algorithm on the host over the SAME 1 GiB (about 4 s of one core)
-    want = orc.Decim(6, sa.FC_CEN, 12).process(x.cpu().numpy())
+    # the reference's algorithm on the host over the SAME 4 GiB (about 15 s of one core)
+    xh = x.cpu().numpy()
+    o = orc.Decim(6, sa.FC_CEN, 12)                          # its C entry point takes the reference's qint32 `len`: feed it in four calls
+    q = n // 4
+    want = np.concatenate([o.process(xh[2 * i * q: 2 * (i + 1) * q]) for i in range(4)])
     assert np.array_equal(whole, want)
     # the same stream as three device-resident calls of uneven size (state carried, group-aligned cuts)
     g.reset()
-    cuts = [0, 64 * 1_000_003, 64 * 3_000_001, n]
+    cuts = [0, 64 * 1_000_003, 64 * 9_000_001, n]
     parts = []
     for a, b in zip(cuts[:-1], cuts[1:]):
         o2 = torch.empty(2 * ((b - a) >> 6) + 64, dtype=torch.int16, device="cuda")
