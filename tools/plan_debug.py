@@ -1,4 +1,5 @@
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""Print the channelizer planner's pass structure for a bench-shaped bank:  SDRX_CHAN_DEBUG=1 python tools/plan_debug.py 256   (needs a GPU: the bank allocates its buffers)"""
 import sdrangel_amd as sa, numpy as np, sys
 n_ch=int(sys.argv[1])
 k=np.arange(n_ch)
