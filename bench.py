@@ -226,12 +226,14 @@ def main():
     x = x.clamp_(-32768, 32767).to(torch.int16)
     del t
     stream = torch.cuda.current_stream(dev).cuda_stream
+    torch.cuda.synchronize(dev)                 # the library's streams are not ordered against torch's default stream (handle 0 = "own stream")
 
     if args.workload == "fi64":
         # DecimatorsFI::decimate64_cen (AirspyHF thread), float I/Q in, int16 Samples out
         xf = (x[: 2 * B].to(torch.float32) / 4096.0).contiguous()
         del x
         x = xf
+        torch.cuda.synchronize(dev)
         h = sa.FloatDecimators("fi", 6, sa.FC_CEN, device=dev.index)
         out = torch.empty(2 * (B >> 6) + 64, dtype=torch.int16, device=dev)
         h.set_stream(stream)

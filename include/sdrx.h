@@ -76,7 +76,9 @@ int sdrx_decim_process(sdrx_decim_t* h, const int16_t* iq, int32_t n_int16,
 int sdrx_decim_process_dev(sdrx_decim_t* h, const int16_t* d_iq, int64_t n_int16,
                            int16_t* d_out_iq, int64_t* n_out_cplx);
 int sdrx_decim_sync(sdrx_decim_t* h);
-/* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = handle's own stream */
+/* run on a caller-owned hipStream_t; NULL = the handle's own (non-blocking) stream.  The HIP default stream has the
+ * handle value 0 and is therefore NOT selectable: work queued on it (PyTorch's default stream) is not ordered against the
+ * handle's stream -- synchronise, or hand over a real stream object. */
 int sdrx_decim_set_stream(sdrx_decim_t* h, void* hip_stream);
 /* #int16 consumed per loop iteration of the matching reference function (its `pos +=`) */
 int sdrx_decim_group_int16(int log2_decim, int fcpos);

@@ -59,6 +59,14 @@ struct sdrx_fdecim {
     float scale = 1.0f;
     int cus = 256;
     fd_chain_fn chain = nullptr;
+    // chains longer than 3 stages run as two passes (stages 1..ns1, then ns1+1..ns through a float intermediate in HBM):
+    // every stage is the same myDecimate(), so decimate64 == decimate8 of decimate8, bit for bit, and in a 3-stage pass
+    // all 256 lanes have work in every stage (4 / 2 / 1 outputs), where stages 4..6 of a single pass idle 1/2 .. 7/8 of them
+    int ns1 = 0, ns2 = 0;
+    fd_chain_fn chain2 = nullptr;
+    float2* d_hist2[2] = { nullptr, nullptr };
+    int hist2_len = 0, cur2 = 0;
+    DevBuf d_mid;
     hipStream_t own_stream = nullptr, stream = nullptr;
     float2* d_hist[2] = { nullptr, nullptr };
     int hist_len = 0, cur = 0;
@@ -85,24 +93,46 @@ static int launch(sdrx_fdecim* h, const void* d_in, long n_groups, void* d_out, 
         h->last_grid = (int)grid; h->last_block = block; h->last_lds = 0;
         return h->timer.end(h->stream);
     }
-    const long n_chunks = (n_pre + FD_CHUNK - 1) / FD_CHUNK;
-    if (n_chunks > 0x7fffffffL / 4) { set_error("sdrx_fdecim: input too long for one call"); return SDRX_EINVAL; }
-    const int warm = fd_warm_chunks(h->ns);
-    const int lds = fd_lds_floats(h->ns) * 4;
-    const int wg_per_cu = std::max(1, std::min(8, (160 * 1024) / std::max(lds, 1)));
-    const int cps = choose_cps(n_chunks, h->cus * wg_per_cu, warm);
-    const long segs = (n_chunks + cps - 1) / cps;
-    hipLaunchKernelGGL(h->chain, dim3((unsigned)segs), dim3(FD_THREADS), 0, h->stream,
-                       h->d_hist[h->cur], d_in, d_out, n_pre, n_out, (int)n_chunks, cps, h->fe, h->out_kind, h->scale);
-    SDRX_HIP(hipGetLastError());
-    snprintf(h->last_name, sizeof h->last_name, "fdecim_chain_kernel<%d,%d>", h->ns, h->in_kind);
-    h->last_grid = (int)segs; h->last_block = FD_THREADS; h->last_lds = lds;
+    auto run_pass = [&](fd_chain_fn fn, int ns, const float2* hist, const void* in, void* out, long np, int fe, int out_kind, float scale, int* grid_out) -> int {
+        const long n_chunks = (np + FD_CHUNK - 1) / FD_CHUNK;
+        if (n_chunks > 0x7fffffffL / 4) { set_error("sdrx_fdecim: input too long for one call"); return SDRX_EINVAL; }
+        const int warm = fd_warm_chunks(ns);
+        const int lds = fd_lds_floats(ns) * 4;
+        const int wg_per_cu = std::max(1, std::min(8, (160 * 1024) / std::max(lds, 1)));
+        const int cps = choose_cps(n_chunks, h->cus * wg_per_cu, warm);
+        const long segs = (n_chunks + cps - 1) / cps;
+        hipLaunchKernelGGL(fn, dim3((unsigned)segs), dim3(FD_THREADS), 0, h->stream, hist, in, out, np, np >> ns, (int)n_chunks, cps, fe, out_kind, scale);
+        SDRX_HIP(hipGetLastError());
+        if (grid_out) *grid_out = (int)segs;
+        return SDRX_OK;
+    };
+    int rc;
+    if (h->ns2 == 0) {
+        rc = run_pass(h->chain, h->ns, h->d_hist[h->cur], d_in, d_out, n_pre, h->fe, h->out_kind, h->scale, &h->last_grid); if (rc) return rc;
+        snprintf(h->last_name, sizeof h->last_name, "fdecim_chain_kernel<%d,%d>", h->ns, h->in_kind);
+        h->last_lds = fd_lds_floats(h->ns) * 4;
+    } else {
+        const long n_mid = n_pre >> h->ns1;
+        rc = h->d_mid.reserve((size_t)std::max<long>(n_mid, 1) * sizeof(float2)); if (rc) return rc;
+        rc = run_pass(h->chain, h->ns1, h->d_hist[h->cur], d_in, h->d_mid.p, n_pre, h->fe, 1, 1.0f, &h->last_grid); if (rc) return rc;
+        rc = run_pass(h->chain2, h->ns2, h->d_hist2[h->cur2], h->d_mid.p, d_out, n_mid, FD_FE_ID, h->out_kind, h->scale, nullptr); if (rc) return rc;
+        snprintf(h->last_name, sizeof h->last_name, "fdecim_chain_kernel<%d,%d> + <%d,0>", h->ns1, h->in_kind, h->ns2);
+        h->last_lds = fd_lds_floats(h->ns1) * 4;
+    }
+    h->last_block = FD_THREADS;
     trc = h->timer.end(h->stream); if (trc) return trc;
     const unsigned hg = (unsigned)((h->hist_len + 255) / 256);
     if (h->in_kind == 0) hipLaunchKernelGGL(fd_hist_update_kernel<0>, dim3(hg), dim3(256), 0, h->stream, h->d_hist[h->cur], d_in, h->d_hist[h->cur ^ 1], n_pre, h->hist_len, h->fe);
     else                 hipLaunchKernelGGL(fd_hist_update_kernel<1>, dim3(hg), dim3(256), 0, h->stream, h->d_hist[h->cur], d_in, h->d_hist[h->cur ^ 1], n_pre, h->hist_len, h->fe);
     SDRX_HIP(hipGetLastError());
     h->cur ^= 1;
+    if (h->ns2) {
+        const unsigned hg2 = (unsigned)((h->hist2_len + 255) / 256);
+        hipLaunchKernelGGL(fd_hist_update_kernel<0>, dim3(hg2), dim3(256), 0, h->stream, h->d_hist2[h->cur2], h->d_mid.p, h->d_hist2[h->cur2 ^ 1],
+                           n_pre >> h->ns1, h->hist2_len, (int)FD_FE_ID);
+        SDRX_HIP(hipGetLastError());
+        h->cur2 ^= 1;
+    }
     return SDRX_OK;
 }
 
@@ -137,11 +167,18 @@ int sdrx_fdecim_create(sdrx_fdecim_t** out, int device, int log2_decim, int fcpo
     // DecimatorsIF: decimation_scale<InputBits>::scaleIn (decimatorsif.cpp)
     h->scale = in_kind == 1 ? (input_bits == 8 ? (float)(1.0 / 128.0) : input_bits == 12 ? (float)(1.0 / 2048.0) : (float)(1.0 / 32768.0)) : 1.0f;
     h->cus = device_cu_count(device);
-    if (h->ns) h->chain = in_kind == 0 ? chain_for<0>(h->ns) : chain_for<1>(h->ns);
+    { const char* sp = getenv("SDRX_FDECIM_SPLIT"); if (h->ns > 3 && !(sp && atoi(sp) == 0)) { h->ns1 = 3; h->ns2 = h->ns - 3; } else { h->ns1 = h->ns; h->ns2 = 0; } }
+    if (h->ns) h->chain = in_kind == 0 ? chain_for<0>(h->ns1) : chain_for<1>(h->ns1);
+    if (h->ns2) h->chain2 = chain_for<0>(h->ns2);
     hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
     h->stream = h->own_stream;
-    h->hist_len = h->ns ? fd_warm_chunks(h->ns) * FD_CHUNK : 0;
+    h->hist_len = h->ns ? fd_warm_chunks(h->ns1) * FD_CHUNK : 0;
+    h->hist2_len = h->ns2 ? fd_warm_chunks(h->ns2) * FD_CHUNK : 0;
+    for (int i = 0; i < 2 && h->hist2_len; i++) {
+        e = hipMalloc(reinterpret_cast<void**>(&h->d_hist2[i]), (size_t)h->hist2_len * sizeof(float2));
+        if (e != hipSuccess) { sdrx_fdecim_destroy(h); return hip_fail(e, "hipMalloc(hist2)", __FILE__, __LINE__); }
+    }
     for (int i = 0; i < 2 && h->hist_len; i++) {
         e = hipMalloc(reinterpret_cast<void**>(&h->d_hist[i]), (size_t)h->hist_len * sizeof(float2));
         if (e != hipSuccess) { sdrx_fdecim_destroy(h); return hip_fail(e, "hipMalloc(hist)", __FILE__, __LINE__); }
@@ -155,8 +192,8 @@ int sdrx_fdecim_destroy(sdrx_fdecim_t* h)
     if (!h) return SDRX_OK;
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-    for (int i = 0; i < 2; i++) if (h->d_hist[i]) (void)hipFree(h->d_hist[i]);
-    h->d_in.release(); h->d_out.release(); h->timer.release();
+    for (int i = 0; i < 2; i++) { if (h->d_hist[i]) (void)hipFree(h->d_hist[i]); if (h->d_hist2[i]) (void)hipFree(h->d_hist2[i]); }
+    h->d_in.release(); h->d_out.release(); h->d_mid.release(); h->timer.release();
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return SDRX_OK;
@@ -167,6 +204,7 @@ int sdrx_fdecim_reset(sdrx_fdecim_t* h)
     if (!h) return SDRX_EINVAL;
     SDRX_HIP(hipSetDevice(h->device));
     if (h->hist_len) SDRX_HIP(hipMemsetAsync(h->d_hist[h->cur], 0, (size_t)h->hist_len * sizeof(float2), h->stream));
+    if (h->hist2_len) SDRX_HIP(hipMemsetAsync(h->d_hist2[h->cur2], 0, (size_t)h->hist2_len * sizeof(float2), h->stream));
     return SDRX_OK;
 }
 

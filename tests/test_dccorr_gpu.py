@@ -37,6 +37,7 @@ def test_device_path_large_and_dc_removed():
     n = 32 * 1024 * 1024
     x = _x(n, 77, dc=(1234, -777), amp=2047)
     d_in = torch.from_numpy(x).cuda(); d_out = torch.empty_like(d_in)
+    torch.cuda.synchronize()                         # handle 0 (torch's default stream) means "own stream" to the library: not ordered with it
     g = sa.DcCorrection(); g.set_stream(torch.cuda.current_stream().cuda_stream)
     g.process_dev(d_in.data_ptr(), d_out.data_ptr(), n)
     torch.cuda.synchronize()

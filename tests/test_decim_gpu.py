@@ -79,6 +79,7 @@ def test_decim_device_path_large():
     n = 10_000_000
     x = orc.synth_iq(n, seed=11, amp=2047, tone=(0.0005, 1000))
     d_in = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()                         # handle 0 (torch's default stream) means "own stream" to the library: not ordered with it
     d_out = torch.empty(2 * (n >> 6) + 64, dtype=torch.int16, device="cuda")
     g = sa.Decimators(6, sa.FC_CEN, 12)
     g.set_stream(torch.cuda.current_stream().cuda_stream)

@@ -17,7 +17,11 @@ def _dev_noise(n_cplx, seed, amp=2047):
     t = torch.arange(n_cplx, device="cuda", dtype=torch.float32)
     x[0::2] += (500 * torch.cos(2 * torch.pi * 0.0007 * t)).to(torch.int32)
     x[1::2] += (500 * torch.sin(2 * torch.pi * 0.0007 * t)).to(torch.int32)
-    return x.clamp_(-32768, 32767).to(torch.int16)
+    x = x.clamp_(-32768, 32767).to(torch.int16)
+    # torch's default stream has the handle 0, which the library reads as "use the handle's own stream": the two are not
+    # ordered against each other, so the generated data has to be complete before the library is pointed at it
+    torch.cuda.synchronize()
+    return x
 
 
 def test_decim64_bench_batch_bit_exact_and_split_invariant():
@@ -37,7 +41,8 @@ def test_decim64_bench_batch_bit_exact_and_split_invariant():
     o = orc.Decim(6, sa.FC_CEN, 12)                          # its C entry point takes the reference's qint32 `len`: feed it in four calls
     q = n // 4
     want = np.concatenate([o.process(xh[2 * i * q: 2 * (i + 1) * q]) for i in range(4)])
-    assert np.array_equal(whole, want)
+    bad = np.nonzero(whole != want)[0] if whole.size == want.size else np.arange(1)
+    assert bad.size == 0, (whole.size, want.size, bad.size, bad[:8].tolist(), bad[-4:].tolist())
     # the same stream as three device-resident calls of uneven size (state carried, group-aligned cuts)
     g.reset()
     cuts = [0, 64 * 1_000_003, 64 * 9_000_001, n]
@@ -54,6 +59,7 @@ def test_fi64_bench_batch_bit_exact():
     """SURVEY 8f.4 at the bench's batch: DecimatorsFI::decimate64_cen over 128 Mi float samples"""
     n = 128 * 1024 * 1024
     x = (_dev_noise(n, 77).to(torch.float32) / 4096.0).contiguous()
+    torch.cuda.synchronize()
     out = torch.empty(2 * (n >> 6) + 64, dtype=torch.int16, device="cuda")
     g = sa.FloatDecimators("fi", 6, sa.FC_CEN)
     g.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -94,6 +100,7 @@ def test_dc_level_through_every_chain_length():
     n = 1 << 22
     x = torch.full((2 * n,), 1000, dtype=torch.int16, device="cuda")
     x[1::2] = -700
+    torch.cuda.synchronize()
     for log2 in range(1, 7):
         g = sa.Decimators(log2, sa.FC_CEN, 12)
         out = torch.empty(2 * (n >> log2) + 64, dtype=torch.int16, device="cuda")
