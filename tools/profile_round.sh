@@ -16,9 +16,9 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_chan32 -- python3 bench.py --workload chan32 --no-cpu --steps 3 --warmup 1 > $O/pmc_fetch_chan32.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_chan32 -- python3 bench.py --workload chan32 --no-cpu --steps 3 --warmup 1 > $O/pmc_write_chan32.log 2>&1
 # cfg 4 (256 channels + demod front) and the float decimators
-timeout -k 10 300 python bench.py --workload cfg4 --batch 67108864 --steps 5 --no-cpu > $O/bench_cfg4.json 2> $O/bench_cfg4.err; cat $O/bench_cfg4.json
+timeout -k 10 300 python bench.py --workload cfg4 --steps 5 --no-cpu > $O/bench_cfg4.json 2> $O/bench_cfg4.err; cat $O/bench_cfg4.json
 timeout -k 10 300 python bench.py --workload fi64 > $O/bench_fi64.json 2> $O/bench_fi64.err; cat $O/bench_fi64.json
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg4 -- python3 bench.py --workload cfg4 --batch 67108864 --no-cpu --steps 5 > $O/trace_cfg4.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg4 -- python3 bench.py --workload cfg4 --no-cpu --steps 5 > $O/trace_cfg4.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_fi64 -- python3 bench.py --workload fi64 --no-cpu --steps 10 > $O/trace_fi64.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_fi64 -- python3 bench.py --workload fi64 --no-cpu --steps 3 --warmup 1 > $O/pmc_fetch_fi64.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_fi64 -- python3 bench.py --workload fi64 --no-cpu --steps 3 --warmup 1 > $O/pmc_write_fi64.log 2>&1
