@@ -337,9 +337,10 @@ __global__ void __launch_bounds__(256) be_fir_kernel(const BeChan* __restrict__ 
         int ph = (int)floorf(__uint_as_float(e.y) * (float)s.phase_steps);     // Interpolator::decimate's phase (interpolator.h:33)
         ph = valid && ph > 0 ? ph : 0;
         const int nt = s.ntaps;
-        int kmin = valid ? k : 0x7fffffff, kmax = valid ? k : -0x7fffffff;
-        for (int d = 32; d; d >>= 1) { kmin = min(kmin, __shfl_xor(kmin, d, 64)); kmax = max(kmax, __shfl_xor(kmax, d, 64)); }
-        kmin = __builtin_amdgcn_readfirstlane(kmin); kmax = __builtin_amdgcn_readfirstlane(kmax);
+        // k grows with the output index (every emission consumes at least one input): the window's ends are the first and the
+        // last valid output's k -- two uniform LDS reads instead of a 12-step cross-lane min/max
+        const int last_lane = min(63, n_res - 1 - o0);
+        const int kmin = (int)tile[0][col].x, kmax = (int)tile[last_lane][col].x;
         const int win = kmax - kmin + nt;
         const bool x_lds = win <= BE_FIR_XCAP;
         const float* tg = taps + s.taps_off + ph * nt;
