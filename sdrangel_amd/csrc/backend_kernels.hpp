@@ -10,9 +10,10 @@
 // (no FMA contraction), correctly rounded division, denormals on.  Cosine/twiddle/tap tables are
 // computed on the host with the same double-precision libm calls the reference makes and uploaded.
 //
-// These streams run at channel rate (tens of kS/s per channel); they are latency/launch bound, not
-// bandwidth bound, so the kernels are written for exactness and clarity: one lane per output sample
-// for the FIR (sequential tap order), one 128-thread workgroup per 1024-point FFT block.
+// These streams run at channel rate (tens of kS/s per channel, hundreds of channels per device stream).  What bounds
+// them: the resampler schedule is a serial float recurrence (closed form when the ratio is dyadic), the
+// polyphase FIR is 72 taps per output and runs from LDS (tile of 64 outputs x 16 channels, tap table staged once per
+// workgroup), the fftfilt block is two 1024/2048-point g_fft passes in LDS per 512/1024 outputs.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
