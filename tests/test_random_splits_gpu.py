@@ -9,7 +9,9 @@ import sdrangel_amd as sa
 from tests import oracle_py as orc
 
 pytestmark = pytest.mark.gpu
-SET = dict(max_examples=30, deadline=None, derandomize=True, database=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
+import os
+N_EX = int(os.environ.get("SDRX_HYP_EXAMPLES", "30"))           # a soak run sets this to a few hundred and drops derandomize
+SET = dict(max_examples=N_EX, deadline=None, derandomize=N_EX <= 30, database=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
 
 
 def _cuts(draw, n, k):
@@ -67,3 +69,33 @@ def test_float_decimators_any_cuts(data):
         seg = x[a:b]
         got, want = g.decimate(seg), o.process(seg)
         assert got.size == want.size and np.array_equal(got.view(np.uint8), want.view(np.uint8)), (kind, bits, log2, fc, a, b)
+
+
+@settings(**SET)
+@given(st.data())
+def test_backend_any_ratio_any_cuts(data):
+    """the demod front with random resampling ratios (dyadic ones take the closed-form schedule, the others the serial walk),
+    every filter mode, and feeds cut anywhere -- 0 ulp against the oracle"""
+    n_ch = data.draw(st.integers(1, 3))
+    cfgs = []
+    for _ in range(n_ch):
+        out_rate = data.draw(st.sampled_from([48000, 44100, 24000, 37123]))
+        mult = data.draw(st.sampled_from([1.0, 1.25, 1.5625, 2.5, 1.302083, 3.0, 1.1, 2.0, 5.0]))
+        in_rate = int(round(out_rate * mult))
+        mode = data.draw(st.integers(0, 6))
+        f1, f2 = (0.04, 0.35) if mode >= 5 else (0.0, 0.12) if mode == 4 else (300 / 48000, 3000 / 48000)
+        cfgs.append(dict(in_rate=in_rate, nco_freq=data.draw(st.integers(-20000, 20000)), out_rate=out_rate,
+                         interp_cutoff=data.draw(st.sampled_from([3000.0, 5681.8, 9000.0])), taps_per_phase=data.draw(st.sampled_from([2.0, 4.5])),
+                         filt_mode=mode, f1=f1, f2=f2, discri=data.draw(st.integers(0, 1)), fm_scaling=12.0))
+    gpu = sa.BackendBank([sa.BackendCfg(**c) for c in cfgs])
+    ora = [orc.Backend(c["in_rate"], c["nco_freq"], c["out_rate"], c["interp_cutoff"], c["taps_per_phase"],
+                       c["filt_mode"], c["f1"], c["f2"], c["discri"], c["fm_scaling"]) for c in cfgs]
+    n = data.draw(st.integers(1, 30000))
+    xs = [orc.synth_iq(n, seed=data.draw(st.integers(0, 1 << 20)), amp=12000) for _ in range(n_ch)]
+    cuts = _cuts(data.draw, n, 3)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        segs = [x[2 * a: 2 * b] for x in xs]
+        gpu.feed(segs)
+        for c in range(n_ch):
+            want, got = ora[c].feed(segs[c]), gpu.read(c)
+            assert got.size == want.size and np.array_equal(got.view(np.uint32), want.view(np.uint32)), (cfgs[c], a, b)
