@@ -8,6 +8,7 @@
 #include "dsp/downchannelizer.h"
 #include "dsp/dspcommands.h"
 #include "util/messagequeue.h"
+#include "dsp/samplesinkfifo.h"
 
 namespace {
 
@@ -78,3 +79,38 @@ int64_t refqt_chan_feed(void* p, const int16_t* iq, int64_t n_cplx, int16_t* out
 }
 
 } // extern "C"
+
+
+// The real SampleSinkFifo (sdrbase/dsp/samplesinkfifo.{h,cpp}), for pinning the sdrx_fifo_* mirror: write / fill /
+// readBegin (two spans, reported as offsets into the ring and lengths) / readCommit / read.
+extern "C" {
+void* refqt_fifo_new(int size) { return new SampleSinkFifo(size); }
+void refqt_fifo_free(void* p) { delete static_cast<SampleSinkFifo*>(p); }
+unsigned refqt_fifo_fill(void* p) { return static_cast<SampleSinkFifo*>(p)->fill(); }
+unsigned refqt_fifo_write(void* p, const int16_t* iq, unsigned n_cplx)
+{
+    SampleVector v(n_cplx);
+    for (unsigned i = 0; i < n_cplx; i++) v[i] = Sample(iq[2*i], iq[2*i+1]);
+    return static_cast<SampleSinkFifo*>(p)->write(v.begin(), v.end());
+}
+unsigned refqt_fifo_write_bytes(void* p, const uint8_t* data, unsigned n_bytes) { return static_cast<SampleSinkFifo*>(p)->write(data, n_bytes); }
+unsigned refqt_fifo_read(void* p, int16_t* out, unsigned n_cplx)
+{
+    SampleVector v(n_cplx);
+    const unsigned n = static_cast<SampleSinkFifo*>(p)->read(v.begin(), v.end());
+    for (unsigned i = 0; i < n; i++) { out[2*i] = v[i].real(); out[2*i+1] = v[i].imag(); }
+    return n;
+}
+// copies what the two spans hold into out (span 1 then span 2); returns the total, *n1 / *n2 the span lengths
+unsigned refqt_fifo_read_begin(void* p, unsigned count, int16_t* out, unsigned* n1, unsigned* n2)
+{
+    SampleVector::iterator b1, e1, b2, e2;
+    const unsigned tot = static_cast<SampleSinkFifo*>(p)->readBegin(count, &b1, &e1, &b2, &e2);
+    *n1 = (unsigned)(e1 - b1); *n2 = (unsigned)(e2 - b2);
+    unsigned k = 0;
+    for (SampleVector::iterator it = b1; it != e1; ++it, ++k) { out[2*k] = it->real(); out[2*k+1] = it->imag(); }
+    for (SampleVector::iterator it = b2; it != e2; ++it, ++k) { out[2*k] = it->real(); out[2*k+1] = it->imag(); }
+    return tot;
+}
+unsigned refqt_fifo_read_commit(void* p, unsigned count) { return static_cast<SampleSinkFifo*>(p)->readCommit(count); }
+}

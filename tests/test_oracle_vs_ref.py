@@ -194,3 +194,19 @@ def test_dc_offset_correction_vs_moving_average_util():
         R.ref_dccorr_process(h, x.ctypes.data, n, want.ctypes.data)
         assert np.array_equal(o.process(x), want[: 2 * n]), n
     R.ref_dccorr_free(h)
+
+
+def test_sample_sink_fifo_mirror_vs_the_real_class():
+    """sdrx_fifo_* against the reference's SampleSinkFifo (QObject, built with moc into oracle/_ref/libsdrref_qt.so): 2400
+    random write / write(bytes) / read / readBegin / readCommit operations incl. overflow and underflow.  Child process:
+    conda's Qt pulls an older libstdc++ unless the system one is preloaded."""
+    import subprocess, sys
+    so = os.path.join(ROOT, "oracle", "_ref", "libsdrref_qt.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libsdrref_qt.so not built")
+    env = dict(os.environ)
+    pre = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
+    if os.path.exists(pre):
+        env["LD_PRELOAD"] = pre
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fifo_vs_reference.py")], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "operations agree" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
