@@ -9,6 +9,8 @@
 #include "dsp/dspcommands.h"
 #include "util/messagequeue.h"
 #include "dsp/samplesinkfifo.h"
+#include "dsp/filerecord.h"
+#include <fstream>
 
 namespace {
 
@@ -113,4 +115,32 @@ unsigned refqt_fifo_read_begin(void* p, unsigned count, int16_t* out, unsigned* 
     return tot;
 }
 unsigned refqt_fifo_read_commit(void* p, unsigned count) { return static_cast<SampleSinkFifo*>(p)->readCommit(count); }
+}
+
+
+// The real FileRecord (sdrbase/dsp/filerecord.{h,cpp}) as the .sdriq writer / header reader, for pinning sdrx_sdriq_*:
+// the sink is told the rate and centre frequency the way the engine tells it (DSPSignalNotification), records one feed.
+extern "C" {
+int refqt_filerecord_write(const char* path, int rate, long long centre, const int16_t* iq, unsigned n_cplx)
+{
+    FileRecord fr;
+    fr.setFileName(QString::fromUtf8(path));
+    DSPSignalNotification sig(rate, centre);
+    fr.handleMessage(sig);
+    fr.startRecording();
+    SampleVector v(n_cplx);
+    for (unsigned i = 0; i < n_cplx; i++) v[i] = Sample(iq[2*i], iq[2*i+1]);
+    fr.feed(v.begin(), v.end(), false);
+    fr.stopRecording();
+    return 0;
+}
+int refqt_filerecord_read_header(const char* path, int* rate, unsigned long long* centre, long long* ts, unsigned* sample_size)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) return -1;
+    FileRecord::Header h;
+    FileRecord::readHeader(f, h);
+    *rate = h.sampleRate; *centre = h.centerFrequency; *ts = (long long) h.startTimeStamp; *sample_size = h.sampleSize;
+    return 0;
+}
 }

@@ -54,3 +54,26 @@ for size in (1, 7, 64, 1000):
         n_ops += 1
     q.refqt_fifo_free(ref)
 print("fifo vs reference:", n_ops, "operations agree")
+
+# ---- .sdriq: the reference's FileRecord writes a recording, sdrx_sdriq_* reads it; sdrx writes a header, FileRecord::readHeader reads it
+import tempfile
+q.refqt_filerecord_write.restype = C.c_int; q.refqt_filerecord_write.argtypes = [C.c_char_p, C.c_int, C.c_longlong, vp, u32]
+q.refqt_filerecord_read_header.restype = C.c_int
+q.refqt_filerecord_read_header.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong), C.POINTER(C.c_longlong), C.POINTER(u32)]
+tmp = tempfile.mkdtemp()
+x = rng.integers(-32768, 32768, 2 * 5000).astype(np.int16)
+path = os.path.join(tmp, "ref.sdriq").encode()
+assert q.refqt_filerecord_write(path, 2_400_000, 435_123_456, x.ctypes.data, 5000) == 0
+hdr, body = sa.sdriq_parse(open(path, "rb").read())
+assert (hdr.sample_rate, hdr.center_frequency, hdr.sample_size) == (2_400_000, 435_123_456, 16) and hdr.start_timestamp > 1_500_000_000
+assert np.array_equal(body, x)
+mine_path = os.path.join(tmp, "mine.sdriq")
+open(mine_path, "wb").write(sa.sdriq_header_bytes(61_440_000, 1_296_000_000, 1_700_000_123, 16) + x.tobytes())
+r, cf, ts, ss = C.c_int(), C.c_ulonglong(), C.c_longlong(), u32()
+assert q.refqt_filerecord_read_header(mine_path.encode(), C.byref(r), C.byref(cf), C.byref(ts), C.byref(ss)) == 0
+assert (r.value, cf.value, ts.value, ss.value) == (61_440_000, 1_296_000_000, 1_700_000_123, 16)
+open(mine_path, "wb").write(sa.sdriq_header_bytes(48000, 1, 2, 12345))     # garbage sample size: the reference assumes 16 bits
+assert q.refqt_filerecord_read_header(mine_path.encode(), C.byref(r), C.byref(cf), C.byref(ts), C.byref(ss)) == 0 and ss.value == 16
+h2, _ = sa.sdriq_parse(open(mine_path, "rb").read())
+assert h2.sample_size == 16
+print("sdriq vs reference FileRecord: headers and samples agree")

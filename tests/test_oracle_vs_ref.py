@@ -198,7 +198,8 @@ def test_dc_offset_correction_vs_moving_average_util():
 
 def test_sample_sink_fifo_mirror_vs_the_real_class():
     """sdrx_fifo_* against the reference's SampleSinkFifo (QObject, built with moc into oracle/_ref/libsdrref_qt.so): 2400
-    random write / write(bytes) / read / readBegin / readCommit operations incl. overflow and underflow.  Child process:
+    random write / write(bytes) / read / readBegin / readCommit operations incl. overflow and underflow; the same child also
+    checks sdrx_sdriq_* against the reference's FileRecord (a recording it writes, a header it reads).  Child process:
     conda's Qt pulls an older libstdc++ unless the system one is preloaded."""
     import subprocess, sys
     so = os.path.join(ROOT, "oracle", "_ref", "libsdrref_qt.so")
@@ -209,4 +210,4 @@ def test_sample_sink_fifo_mirror_vs_the_real_class():
     if os.path.exists(pre):
         env["LD_PRELOAD"] = pre
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fifo_vs_reference.py")], capture_output=True, text=True, env=env, timeout=300)
-    assert r.returncode == 0 and "operations agree" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
+    assert r.returncode == 0 and "operations agree" in r.stdout and "sdriq vs reference FileRecord" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
