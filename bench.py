@@ -193,7 +193,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="decim64", choices=["decim64", "chan32", "chan128", "cfg4", "fi64"])
     ap.add_argument("--batch", type=int, default=None,
-                    help="complex samples per step per GPU; default per workload: decim64 1 Gi (4 GiB of int16 I/Q), chan32/chan128/cfg4 256 Mi, "
+                    help="complex samples per step per GPU; default per workload: decim64 and chan32 1 Gi (4 GiB of int16 I/Q), chan128/cfg4 256 Mi, "
                          "fi64 512 Mi (4 GiB of float I/Q).  One wave of the decimator lives ~0.3 ms, so short launches lose a "
                          "large part of their time to the tail: 256 Mi samples run at 385 GS/s, 1 Gi at 494 GS/s (DESIGN.md 6)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -216,7 +216,7 @@ def main():
     my_streams = shard.streams_of_rank(n_gpus, rank, world)       # one stream per GPU: stream s -> GPU s
     assert my_streams == [rank]
 
-    B = args.batch if args.batch else {"decim64": 1 << 30, "chan32": 1 << 28, "chan128": 1 << 28, "cfg4": 1 << 28, "fi64": 1 << 29}[args.workload]
+    B = args.batch if args.batch else {"decim64": 1 << 30, "chan32": 1 << 30, "chan128": 1 << 28, "cfg4": 1 << 28, "fi64": 1 << 29}[args.workload]
     g = torch.Generator(device=dev); g.manual_seed(5489 + rank)
     # sdrbench-shaped data: uniform 12-bit noise, I/Q interleaved (mainbench.cpp:76-79) + an in-band tone
     x = torch.randint(-2048, 2048, (2 * B,), generator=g, device=dev, dtype=torch.int32)
@@ -307,7 +307,7 @@ def main():
         }
         if n_gpus == 1 and args.workload == "decim64" and not args.no_also:
             # the other half of the metric's name: BASELINE configs[2], 32-channel DownChannelizer bank, same GPU, same run
-            nb = min(B, 256 * 1024 * 1024)
+            nb = B                                         # the same resident buffer
             k32 = torch.arange(32, dtype=torch.float64)
             fcs32 = (-15_000_000 + k32 * (30_000_000 / 31) + 137 * k32).to(torch.int64).tolist()
             bank = sa.ChannelizerBank(61_440_000, [48000] * 32, fcs32, device=dev.index)
