@@ -174,7 +174,7 @@ static int launch(sdrx_decim* h, const void* d_iq, long n_cplx, int16_t* d_out)
         long spw = 32; double best = 1e300;
         const char* env = getenv("SDRX_DECIM_SPW");
         if (env && atoi(env) >= 4) spw = (atoi(env) / 4) * 4;
-        else if (n_sub >= 16 * 32 * slots) spw = 64;          // long launches: halve the warm-up share (1 Gi samples: 494 vs 471 GS/s)
+        else if (n_sub >= 8 * 32 * slots) spw = 64;           // long launches: halve the warm-up share (512 Mi samples: 429 vs 418 GS/s, 1 Gi: 494 vs 471)
         else if (n_sub < 32 * slots) for (long c = 4; c <= 32; c += 4) {
             const long segs = (n_sub + c - 1) / c, rounds = (segs + slots - 1) / slots;
             const double cost = (double)(c + DF_WARM) * (double)rounds;
