@@ -271,7 +271,10 @@ __global__ void be_mix_kernel(const BeChan* __restrict__ ch, const BeBufs* __res
 // independent (wave-private windows, wave-level ordering only), so one wave's staging latency overlaps the others' taps.
 constexpr int BE_FIR_TO = 64, BE_FIR_TC = 16;
 constexpr int BE_FIR_XCAP = 384;                            // float2 per wave: 64 * (inputs per output) + nt
-constexpr int BE_FIR_NT_MAX = 80, BE_FIR_TCAP = 16 * (BE_FIR_NT_MAX + 1);
+constexpr int BE_FIR_NT_MAX = 80, BE_FIR_TCAP = 16 * (BE_FIR_NT_MAX + 8);
+// tap-table row pitch: a multiple of 4 floats whose quarter is odd -- rows start 16-byte aligned (float4 reads) and the 16
+// phases read at the same tap index fall into 16 different 4-bank groups
+__host__ __device__ constexpr int be_fir_pitch(int nt) { const int p = (nt + 3) & ~3; return (p / 4) % 2 ? p : p + 4; }
 __device__ __forceinline__ void be_wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -282,8 +285,19 @@ template <bool XL, bool TL>                                 // input window / ta
 __device__ __forceinline__ float2 be_fir_taps(const float2* x, const float* t, int nt)
 {
     float ra = 0.0f, ia = 0.0f;
+    int i = 0;
+    if constexpr (TL) {                                      // LDS table: rows are 16-byte aligned, four taps per ds_read_b128
+        for (; i + 4 <= nt; i += 4) {
+            const float4 c = *reinterpret_cast<const float4*>(t + i);
+            const float2 v0 = x[-i], v1 = x[-i - 1], v2 = x[-i - 2], v3 = x[-i - 3];
+            ra += c.x * v0.x; ia += c.x * v0.y;
+            ra += c.y * v1.x; ia += c.y * v1.y;
+            ra += c.z * v2.x; ia += c.z * v2.y;
+            ra += c.w * v3.x; ia += c.w * v3.y;
+        }
+    }
 #pragma unroll 8
-    for (int i = 0; i < nt; i++) {
+    for (; i < nt; i++) {
         const float2 v = x[-i];
         ra += t[i] * v.x;
         ia += t[i] * v.y;
@@ -296,7 +310,7 @@ __global__ void __launch_bounds__(256) be_fir_kernel(const BeChan* __restrict__ 
 {
     __shared__ uint2 tile[BE_FIR_TO][BE_FIR_TC + 1];
     __shared__ float2 xw_all[4][BE_FIR_XCAP];
-    __shared__ float tw[BE_FIR_TCAP];
+    __shared__ __attribute__((aligned(16))) float tw[BE_FIR_TCAP];
     const int o0 = blockIdx.x * BE_FIR_TO, q0 = blockIdx.y * BE_FIR_TC;
     const int q_end = min(q0 + BE_FIR_TC, n_ch);
     int n_res_max = 0;
@@ -315,7 +329,7 @@ __global__ void __launch_bounds__(256) be_fir_kernel(const BeChan* __restrict__ 
         if (q0 + col < n_ch && o0 + row < n_res_max) tile[row][col] = sched[(long)(o0 + row) * n_ch + q0 + col];
     }
     if (shared) {
-        const int pitch = nt0 | 1;
+        const int pitch = be_fir_pitch(nt0);
         const float* tg = taps + off0;
         for (int q = threadIdx.x >> 6; q < 16; q += 4)
             for (int i = threadIdx.x & 63; i < nt0; i += 64) tw[q * pitch + i] = tg[q * nt0 + i];
@@ -345,7 +359,7 @@ __global__ void __launch_bounds__(256) be_fir_kernel(const BeChan* __restrict__ 
         const int win = kmax - kmin + nt;
         const bool x_lds = win <= BE_FIR_XCAP;
         const float* tg = taps + s.taps_off + ph * nt;
-        const float* tl = tw + ph * (nt | 1);
+        const float* tl = tw + ph * be_fir_pitch(nt);
         const float2* xg = b.mixed + BE_HIST;
         if (x_lds) {
             const float2* src = xg + (kmin - nt + 1);
