@@ -1,28 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the sdrx hot path on MI355X, one JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload decim64|chan32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|decim64|chan32|chan128|cfg4|fi64]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is ONE pass of the hot path over one batch of synthetic int16 I/Q that is already resident
-in HBM: `sdrx_decim_process_dev` (decimate64_cen, Decimators<qint32,qint16,16,12>, BASELINE.json
-configs[1]) over a batch of 256 Mi complex samples (1 GiB) of one stream.  With N > 1 every rank owns one
-GPU and one independent stream (streams shard, no collective on the data path);
-per-GPU work is fixed, so scaling is "weak" and `value` is the sum over ranks.
+`--gpus N` with N > 1 and no torchrun around it: bench.py itself starts N worker processes (one per GPU, RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) BEFORE anything touches HIP, and rank 0 prints the line.
+On a box with fewer GPUs than ranks the workers rendezvous over gloo and share the cards (a rehearsal, flagged).
 
-roofline : dominant kernel's ALGORITHMIC bytes (4 B read + 4/64 B written per input sample =
-           4.0625 B/sample) / its average duration, measured with HIP events on the
-           launch stream inside the library (sdrx_decim_get_timing), against 8 TB/s HBM3E.
-cpu_baseline : the reference's own decimate64_cen (oracle/_ref/libsdrref.so, built from
-           /root/reference in the build container; kind "reference") or, if that .so did not travel,
-           the oracle port (oracle/libsdro_fast.so; kind "port"), one independent stream per thread
-           on the host cores of this box, bounded sample.  The oracle is only the checker/baseline:
-           nothing on the measured GPU path touches it.
+A "step" of the default (headline) workload is ONE pass of the metric's path over one batch of synthetic int16
+I/Q already resident in HBM:   decimate64_cen (BASELINE.json configs[1], Decimators<qint32,qint16,16,12>)   AND
+the 32-channel DownChannelizer bank (configs[2], 61.44 MS/s-shaped stream) over the same batch.  `value` =
+samples per second that went through BOTH (batch x steps / elapsed).  Every rank owns one GPU and one independent
+stream (streams shard, no collective on the data path); per-GPU work is fixed -> "weak" scaling.
+`also.chan128` is BASELINE configs[4]'s per-GPU share (128 channels per stream), measured with the same protocol.
+
+roofline : per kernel, ALGORITHMIC bytes (4 B read + 4/2^n B written per input sample and channel)
+           / its average duration from HIP events on the launch stream (sdrx_*_get_timing) against 8 TB/s HBM3E.
+           `frac` of the headline is the LOWER of the two kernels' fractions; `bound` says what the SQ counters
+           show (VALU issue, profiles/), `valu_ceiling_frac` is the HBM fraction at which integer-MAC issue alone
+           (v_dot2c_i32_i16: 2 taps per 4 SIMD cycles, profiles/r01_valu_issue_rates.txt) caps the kernel.
+cpu_baseline : the reference's own code (oracle/_ref/libsdrref_fast.so: the reference's classes compiled from
+           /root/reference with the reference's flags -O3 -ffast-math -ftree-vectorize -msse4.1, built in the
+           build container; kind "reference") or, if that .so did not travel, the oracle port
+           (oracle/libsdro_fast.so; kind "port"), on this box's host cores, bounded sample.  The oracle is only
+           the checker/baseline: nothing on the measured GPU path touches it.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -31,150 +40,172 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E datasheet (MI355X_MICROARCH.md); ~6300 achievable
+# integer MAC issue: 256 CUs x 4 SIMDs x 64 lanes / 4 cycles per v_dot2c (2 taps) at the 2.4 GHz maximum clock
+DOT2_PER_S = 256 * 4 * 16 * 2.4e9
+METRIC = "MS/s complex int16 IQ through decim-64 + DownChannelizer, 1/2/4/8 GPU; % HBM roofline"
 
 
-def cpu_baseline(sample_cplx: int, reps: int, log2: int = 6):
-    """Reference (or port) decimate64_cen, one stream per thread, on the host cores."""
+# ------------------------------------------------------------------------------------------------ host side
+def host_threads():
+    """threads the CPU baseline may use: the cores this process is allowed on (cpuset / cgroup quota aware)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _ref_lib():
+    """(lib, kind): the reference compiled with its own flags, else the strict reference build, else None"""
+    for name in ("libsdrref_fast.so", "libsdrref.so"):
+        p = os.path.join(ROOT, "oracle", "_ref", name)
+        if os.path.exists(p):
+            try:
+                L = C.CDLL(p)
+                L.ref_decim_new.restype = C.c_void_p; L.ref_decim_new.argtypes = [C.c_int]
+                L.ref_decim_process.restype = C.c_int
+                L.ref_decim_process.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int32, C.c_void_p]
+                L.ref_chain_new.restype = C.c_void_p; L.ref_chain_new.argtypes = [C.c_int, C.c_void_p]
+                L.ref_chain_feed.restype = C.c_int64; L.ref_chain_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+                return L, "reference", name
+            except (OSError, AttributeError):
+                continue
+    return None, "port", "libsdro_fast.so"
+
+
+def _port_lib():
+    from tests import oracle_py as orc
+    fast = os.path.join(ROOT, "oracle", "libsdro_fast.so")
+    if not os.path.exists(fast):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libsdro_fast.so"])
+    return orc.lib(fast=True)
+
+
+def _run_threads(n_threads, work):
+    th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+    t0 = time.perf_counter()
+    for t in th: t.start()
+    for t in th: t.join()
+    return time.perf_counter() - t0
+
+
+def cpu_decim(log2: int, sample_cplx: int, reps: int, n_thr: int, seed: int = 1234):
+    """decimateK_cen <16,12> (K = 2^log2): one thread as sdrangelbench runs it (sdrbench/mainbench.cpp:83-104: the same
+    buffer, `reps` repetitions, state carried), then one independent stream per thread on n_thr threads."""
     import numpy as np
     from tests import oracle_py as orc
-    n_thr = max(1, min(os.cpu_count() or 1, 16))
-    x = orc.synth_iq(sample_cplx, seed=1234, amp=2047)
-    ref_so = os.path.join(ROOT, "oracle", "_ref", "libsdrref.so")
-    kind = None
-    if os.path.exists(ref_so):
-        try:
-            L = C.CDLL(ref_so)
-            L.ref_decim_new.restype = C.c_void_p; L.ref_decim_new.argtypes = [C.c_int]
-            L.ref_decim_process.restype = C.c_int
-            L.ref_decim_process.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int32, C.c_void_p]
-            mk = lambda: L.ref_decim_new(12)
-            run = lambda h, buf, out: L.ref_decim_process(h, log2, 2, buf.ctypes.data, buf.size, out.ctypes.data)
-            kind = "reference"
-        except OSError:
-            kind = None
-    if kind is None:
-        fast = os.path.join(ROOT, "oracle", "libsdro_fast.so")
-        if not os.path.exists(fast):
-            import subprocess
-            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libsdro_fast.so"])
-        L = orc.lib(fast=True)
-        mk = lambda: L.sdro_decim_new(log2, 2, 12)
-        run = lambda h, buf, out: L.sdro_decim_process(h, buf.ctypes.data, buf.size, out.ctypes.data)
-        kind = "port"
+    x = orc.synth_iq(sample_cplx, seed=seed, amp=2047)
+    L, kind, so = _ref_lib()
+    if L is not None:
+        mk = lambda: L.ref_decim_new(12)
+        run = lambda h, buf, out: L.ref_decim_process(h, log2, 2, buf.ctypes.data, buf.size, out.ctypes.data)
+    else:
+        P = _port_lib()
+        mk = lambda: P.sdro_decim_new(log2, 2, 12)
+        run = lambda h, buf, out: P.sdro_decim_process(h, buf.ctypes.data, buf.size, out.ctypes.data)
 
-    def timed(n_threads):
-        hs = [mk() for _ in range(n_threads)]
-        bufs = [x.copy() for _ in range(n_threads)]
-        outs = [np.empty(sample_cplx // (1 << log2) * 2 + 64, np.int16) for _ in range(n_threads)]
-        for i in range(n_threads):
+    def timed(nt):
+        hs = [mk() for _ in range(nt)]
+        bufs = [x.copy() for _ in range(nt)]
+        outs = [np.empty(sample_cplx // (1 << log2) * 2 + 64, np.int16) for _ in range(nt)]
+        for i in range(nt):
             run(hs[i], bufs[i][: 2 * 65536], outs[i])          # touch / warm
         def work(i):
             for _ in range(reps):
                 run(hs[i], bufs[i], outs[i])
-        th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
-        t0 = time.perf_counter()
-        for t in th: t.start()
-        for t in th: t.join()
-        dt = time.perf_counter() - t0
-        return n_threads * reps * sample_cplx / dt / 1e6
+        return nt * reps * sample_cplx / _run_threads(nt, work) / 1e6
 
     one = timed(1)
     allc = timed(n_thr) if n_thr > 1 else one
-    return {"value": round(allc, 2), "unit": "MS/s", "cores": n_thr, "kind": kind,
-            "single_thread_MSps": round(one, 2),
-            "sample": f"decimate64_cen <16,12> on {sample_cplx} synthetic int16 I/Q samples x {reps} passes per thread, "
+    return {"value": round(allc, 2), "unit": "MS/s", "cores": n_thr, "kind": kind, "lib": so, "single_thread_MSps": round(one, 2),
+            "sample": f"decimate{1 << log2}_cen <16,12> on {sample_cplx} synthetic int16 I/Q samples x {reps} repetitions per thread, "
                       f"one independent stream per thread ({n_thr} threads); single_thread_MSps = 1 thread, as sdrangelbench runs it"}
 
 
-def cpu_baseline_fi(sample_cplx: int, reps: int):
-    """Reference (or port) DecimatorsFI::decimate64_cen, one stream per thread, on the host cores."""
-    import numpy as np
-    from tests import oracle_py as orc
-    n_thr = max(1, min(os.cpu_count() or 1, 16))
-    x = (orc.synth_iq(sample_cplx, seed=99, amp=2047).astype(np.float32) / np.float32(4096.0))
-    ref_so = os.path.join(ROOT, "oracle", "_ref", "libsdrref.so")
-    kind = "port"
-    L = None
-    if os.path.exists(ref_so):
-        try:
-            L = C.CDLL(ref_so)
-            L.ref_fdecim_new.restype = C.c_void_p; L.ref_fdecim_new.argtypes = [C.c_int] * 3
-            L.ref_fdecim_process.restype = C.c_int; L.ref_fdecim_process.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int32, C.c_void_p]
-            kind = "reference"
-        except (OSError, AttributeError):
-            L = None
-    if L is not None:
-        mk = lambda: L.ref_fdecim_new(0, 0, 16)
-        run = lambda h, out: L.ref_fdecim_process(h, 6, 2, x.ctypes.data, x.size, out.ctypes.data)
-    else:
-        O = orc.lib(); orc._sig_fdecim(O)
-        mk = lambda: O.sdro_fdecim_new(6, 2, 0, 0, 16)
-        run = lambda h, out: O.sdro_fdecim_process(h, x.ctypes.data, x.size, out.ctypes.data)
-
-    def timed(n_threads):
-        hs = [mk() for _ in range(n_threads)]
-        outs = [np.empty(x.size + 64, np.int16) for _ in range(n_threads)]
-        def work(i):
-            for _ in range(reps):
-                run(hs[i], outs[i])
-        th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
-        t0 = time.perf_counter()
-        for t in th: t.start()
-        for t in th: t.join()
-        return n_threads * reps * sample_cplx / (time.perf_counter() - t0) / 1e6
-
-    one = timed(1)
-    allc = timed(n_thr) if n_thr > 1 else one
-    return {"value": round(allc, 2), "unit": "MS/s", "cores": n_thr, "kind": kind, "single_thread_MSps": round(one, 2),
-            "sample": f"DecimatorsFI::decimate64_cen on {sample_cplx} synthetic float I/Q samples x {reps} passes per thread, one stream per thread ({n_thr} threads)"}
-
-
-def cpu_baseline_chan(fcs, sample_cplx: int):
+def cpu_chan(fcs, sample_cplx: int, n_thr: int):
     """Reference DownChannelizer stage chains (IntHalfbandFilterEO<qint32,qint32,48> objects driven by the loop of
     DownChannelizer::feed), every channel re-filtering the full-rate stream on its own thread like
     ThreadedBasebandSampleSink does (threadedbasebandsamplesink.cpp:74-78); value = input MS/s the host sustains
     for the WHOLE bank."""
     import numpy as np
     from tests import oracle_py as orc
-    n_thr = max(1, min(os.cpu_count() or 1, 16, len(fcs)))
+    n_thr = max(1, min(n_thr, len(fcs)))
     x = orc.synth_iq(sample_cplx, seed=77, amp=2047)
-    ref_so = os.path.join(ROOT, "oracle", "_ref", "libsdrref.so")
     plans = [orc.chan_plan(61_440_000, 48000, int(fc))[0] for fc in fcs]
-    kind = "port"
-    L = None
-    if os.path.exists(ref_so):
-        try:
-            L = C.CDLL(ref_so)
-            L.ref_chain_new.restype = C.c_void_p; L.ref_chain_new.argtypes = [C.c_int, C.c_void_p]
-            L.ref_chain_feed.restype = C.c_int64; L.ref_chain_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
-            kind = "reference"
-        except OSError:
-            L = None
+    L, kind, so = _ref_lib()
     if L is not None:
         hs = [L.ref_chain_new(len(m), np.ascontiguousarray(m).ctypes.data) for m in plans]
         feed = lambda h, out: L.ref_chain_feed(h, x.ctypes.data, sample_cplx, out.ctypes.data)
     else:
-        O = orc.lib(fast=os.path.exists(os.path.join(ROOT, "oracle", "libsdro_fast.so")))
-        hs = [O.sdro_chain_new(len(m), np.ascontiguousarray(m).ctypes.data) for m in plans]
-        feed = lambda h, out: O.sdro_chain_feed(h, x.ctypes.data, sample_cplx, out.ctypes.data)
+        P = _port_lib()
+        hs = [P.sdro_chain_new(len(m), np.ascontiguousarray(m).ctypes.data) for m in plans]
+        feed = lambda h, out: P.sdro_chain_feed(h, x.ctypes.data, sample_cplx, out.ctypes.data)
     outs = [np.empty(sample_cplx // 64 + 64, np.int16) for _ in hs]
     def work(t):
         for c in range(t, len(hs), n_thr):
             feed(hs[c], outs[c])
-    th = [threading.Thread(target=work, args=(t,)) for t in range(n_thr)]
-    t0 = time.perf_counter()
-    for t in th: t.start()
-    for t in th: t.join()
-    dt = time.perf_counter() - t0
-    return {"value": round(sample_cplx / dt / 1e6, 3), "unit": "MS/s", "cores": n_thr, "kind": kind,
+    dt = _run_threads(n_thr, work)
+    return {"value": round(sample_cplx / dt / 1e6, 3), "unit": "MS/s", "cores": n_thr, "kind": kind, "lib": so,
             "sample": f"{len(fcs)} DownChannelizer chains (one per channel, each over the full-rate stream) on {sample_cplx} synthetic samples, "
                       f"{n_thr} host threads, channels dealt round-robin; value = input rate sustained for the whole bank"}
 
 
+def cpu_fi(sample_cplx: int, reps: int, n_thr: int):
+    """Reference (or port) DecimatorsFI::decimate64_cen, one stream per thread, on the host cores."""
+    import numpy as np
+    from tests import oracle_py as orc
+    x = (orc.synth_iq(sample_cplx, seed=99, amp=2047).astype(np.float32) / np.float32(4096.0))
+    L, kind, so = _ref_lib()
+    if L is not None:
+        try:
+            L.ref_fdecim_new.restype = C.c_void_p; L.ref_fdecim_new.argtypes = [C.c_int] * 3
+            L.ref_fdecim_process.restype = C.c_int; L.ref_fdecim_process.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int32, C.c_void_p]
+        except AttributeError:
+            L = None
+    if L is not None:
+        mk = lambda: L.ref_fdecim_new(0, 0, 16)
+        run = lambda h, out: L.ref_fdecim_process(h, 6, 2, x.ctypes.data, x.size, out.ctypes.data)
+    else:
+        O = orc.lib(); orc._sig_fdecim(O); kind, so = "port", "libsdro.so"
+        mk = lambda: O.sdro_fdecim_new(6, 2, 0, 0, 16)
+        run = lambda h, out: O.sdro_fdecim_process(h, x.ctypes.data, x.size, out.ctypes.data)
+
+    def timed(nt):
+        hs = [mk() for _ in range(nt)]
+        outs = [np.empty(x.size + 64, np.int16) for _ in range(nt)]
+        def work(i):
+            for _ in range(reps):
+                run(hs[i], outs[i])
+        return nt * reps * sample_cplx / _run_threads(nt, work) / 1e6
+
+    one = timed(1)
+    allc = timed(n_thr) if n_thr > 1 else one
+    return {"value": round(allc, 2), "unit": "MS/s", "cores": n_thr, "kind": kind, "lib": so, "single_thread_MSps": round(one, 2),
+            "sample": f"DecimatorsFI::decimate64_cen on {sample_cplx} synthetic float I/Q samples x {reps} passes per thread, one stream per thread ({n_thr} threads)"}
+
+
 def load_traffic(kernel: str, batch: int, workload: str):
-    """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/*traffic*.json), or None."""
+    """(HBM bytes per step, source file) from the newest committed rocprofv3 --pmc summary (profiles/*traffic*.json) that
+    holds this kernel at this batch; (None, None) otherwise.  PMC passes cannot run inside the timed bench (separate
+    rocprofv3 runs, MI355X_MICROARCH.md), so the figure is labelled with the file it comes from."""
     import glob
-    best = None
+    best = (None, None)
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
         try:
             d = json.load(open(p))
@@ -182,8 +213,65 @@ def load_traffic(kernel: str, batch: int, workload: str):
             continue
         for e in d.get("kernels", []):
             if e.get("workload") == workload and e.get("batch_cplx") == batch and e.get("kernel", "").startswith(kernel.split("<")[0]):
-                best = e.get("hbm_bytes_per_step", e.get("hbm_bytes_per_launch"))
+                best = (e.get("hbm_bytes_per_step", e.get("hbm_bytes_per_launch")), "profiles/" + os.path.basename(p))
     return best
+
+
+# ------------------------------------------------------------------------------------------------ N-rank launcher
+def spawn_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without torchrun: N worker processes, one per GPU.  Called before this process has
+    loaded libsdrx.so / torch or made any HIP call; the workers are plain children (no exec of a GPU-initialised process)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    try:
+        for p in procs:
+            r = p.wait()
+            rc = rc or r
+            if r:                                           # one rank failed: the others would wait at the rendezvous
+                for q in procs:
+                    if q.poll() is None:
+                        q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ main
+def chan_centres(n_ch: int, workload: str):
+    import numpy as np
+    k = np.arange(n_ch, dtype=np.float64)
+    if workload == "cfg4":
+        return (-25_000_000 + k * (50_000_000 / 255)).astype(np.int64).tolist()
+    return (-15_000_000 + k * (30_000_000 / (n_ch - 1)) + 137 * k).astype(np.int64).tolist()     # SURVEY.md 8d, cfg 3
+
+
+def bank_figures(bank, n_ch):
+    """algorithmic bytes per input sample (4 + sum_c 4/2^n_c) and dot2 issue per input sample of the stage trie"""
+    depth = 0.0
+    nodes = {}
+    for c in range(n_ch):
+        modes = tuple(int(m) for m in bank.info(c)[0])
+        depth += 4.0 / (1 << len(modes))
+        for l in range(1, len(modes) + 1):
+            nodes.setdefault(l, set()).add(modes[:l])
+    # order-48 stage: 24 odd-arm taps + centre = 13 dot2 per output and component (12.5 + 1 on average); a node at level l
+    # produces 2^-l outputs per input sample.  Lower/upper siblings share the odd-arm sum (tree_kernel.hpp): 12.5 + 2.
+    d2 = 0.0
+    for l, ns in nodes.items():
+        fused = set()
+        for m in ns:
+            if m[-1] in (1, 2) and (m[:-1] + (3 - m[-1],)) in ns:
+                fused.add(m[:-1])
+        single = len(ns) - 2 * len(fused)
+        d2 += (single * 13.5 + len(fused) * 14.5) * 2 / (1 << l)
+    return 4.0 + depth, d2
 
 
 def main():
@@ -191,32 +279,61 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="decim64", choices=["decim64", "chan32", "chan128", "cfg4", "fi64"])
+    ap.add_argument("--workload", default="headline", choices=["headline", "decim64", "chan32", "chan128", "cfg4", "fi64", "launchcheck"])
     ap.add_argument("--batch", type=int, default=None,
-                    help="complex samples per step per GPU; default per workload: decim64 and chan32 1 Gi (4 GiB of int16 I/Q), chan128/cfg4 256 Mi, "
-                         "fi64 512 Mi (4 GiB of float I/Q).  One wave of the decimator lives ~0.3 ms, so short launches lose a "
-                         "large part of their time to the tail: 256 Mi samples run at 385 GS/s, 1 Gi at 494 GS/s (DESIGN.md 6)")
+                    help="complex samples per step per GPU; default per workload: headline/decim64/chan32 1 Gi (4 GiB of int16 I/Q), "
+                         "chan128/cfg4 256 Mi, fi64 512 Mi (4 GiB of float I/Q)")
+    ap.add_argument("--streams-per-gpu", type=int, default=1,
+                    help="decimator part: split the batch into this many independent device streams served by ONE batched launch "
+                         "(sdrx_decim_process_dev_batch); the bank part keeps one stream")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-also", action="store_true", help="skip the secondary cfg-3 (32-channel bank) measurement")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements")
     args = ap.parse_args()
 
-    import sdrangel_amd as sa
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))       # nothing above touched HIP
+
     from sdrangel_amd import shard
+    rank, local, world = shard.world_from_env()
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.workload == "launchcheck":
+        # the N-rank protocol alone (launcher, rendezvous, barrier + max-over-ranks timing, rank-0 line) with a host-only
+        # step and no GPU work: what tests/test_shard_gloo.py drives on the CPU.  Not a measurement.
+        import numpy as np
+        dist = shard.init_process_group("gloo", rank, world) if world > 1 else None
+        buf = np.arange(1 << 16, dtype=np.int64) + rank
+        acc = []
+        el = shard.timed_region(lambda: acc.append(int(buf.sum())), args.steps, args.warmup, lambda: None, dist=dist)
+        if rank == 0:
+            print(json.dumps({"metric": "launcher self-test (host-only step, no GPU work)", "value": round(world * args.steps * buf.size / el / 1e6, 1),
+                              "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4),
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "selftest",
+                              "config": {"workload": "launchcheck", "streams": world}}), flush=True)
+        if dist is not None:
+            dist.barrier(); dist.destroy_process_group()
+        return
+
+    import sdrangel_amd as sa
     sa.lib()                                    # before torch: one HIP runtime (see sdrangel_amd/__init__.py)
     import torch
-
-    rank, local, world = shard.world_from_env()
-    # SDRX_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share the cards)
-    backend = os.environ.get("SDRX_BENCH_BACKEND", "nccl")
     n_dev = max(torch.cuda.device_count(), 1)
-    dev = torch.device("cuda", (local % n_dev if backend == "gloo" else local) if world > 1 else 0)
+    backend = os.environ.get("SDRX_BENCH_BACKEND", "nccl")
+    rehearsal = world > n_dev                   # fewer GPUs than ranks: ranks share the cards, rendezvous over gloo
+    if rehearsal:
+        backend = "gloo"
+    dev = torch.device("cuda", (local % n_dev) if world > 1 else 0)
     torch.cuda.set_device(dev)
     dist = shard.init_process_group(backend, rank, world, device=dev) if world > 1 else None   # "nccl" == RCCL on ROCm
     n_gpus = world
     my_streams = shard.streams_of_rank(n_gpus, rank, world)       # one stream per GPU: stream s -> GPU s
     assert my_streams == [rank]
+    red_dev = dev if (dist is not None and backend != "gloo") else None
 
-    B = args.batch if args.batch else {"decim64": 1 << 30, "chan32": 1 << 30, "chan128": 1 << 28, "cfg4": 1 << 28, "fi64": 1 << 29}[args.workload]
+    wl = args.workload
+    B = args.batch if args.batch else {"headline": 1 << 30, "decim64": 1 << 30, "chan32": 1 << 30, "chan128": 1 << 28, "cfg4": 1 << 28, "fi64": 1 << 29}[wl]
+    if rehearsal and not args.batch:
+        B = min(B, 1 << 28)
     def make_input(n):
         # sdrbench-shaped data: uniform 12-bit noise, I/Q interleaved (mainbench.cpp:76-79) + an in-band tone
         g = torch.Generator(device=dev); g.manual_seed(5489 + rank)
@@ -225,18 +342,54 @@ def main():
         v[0::2] += (600 * torch.cos(2 * torch.pi * 0.0011 * t)).to(torch.int32)
         v[1::2] += (600 * torch.sin(2 * torch.pi * 0.0011 * t)).to(torch.int32)
         return v.clamp_(-32768, 32767).to(torch.int16)
-    try:
-        x = make_input(B)
-    except torch.cuda.OutOfMemoryError:                      # a device with less free memory than an MI355X: same workload, smaller step
-        if args.batch:
-            raise
-        torch.cuda.empty_cache()
-        B = B // 4
-        x = make_input(B)
+    x = None
+    while x is None:
+        try:
+            x = make_input(B)
+            ok = 1
+        except torch.cuda.OutOfMemoryError:                  # a device with less free memory than an MI355X: same workload, smaller step
+            if args.batch:
+                raise
+            torch.cuda.empty_cache()
+            ok = 0
+        if dist is not None:                                 # every rank runs the same batch: agree on the smallest
+            t = torch.tensor([B if ok else B // 4], dtype=torch.int64, device=red_dev if red_dev is not None else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) != B:
+                B = int(t.item()); x = None; torch.cuda.empty_cache()
+        elif not ok:
+            B //= 4
     stream = torch.cuda.current_stream(dev).cuda_stream
     torch.cuda.synchronize(dev)                 # the library's streams are not ordered against torch's default stream (handle 0 = "own stream")
 
-    if args.workload == "fi64":
+    S = max(1, args.streams_per_gpu)
+    timed_handles = {}                          # name -> (handle, algorithmic bytes per sample, samples per step)
+
+    def make_decim(n):
+        """decimate64_cen over n samples as S independent streams, one (batched) launch"""
+        if S == 1:
+            h = sa.Decimators(6, sa.FC_CEN, 12, device=dev.index)
+            out = torch.empty(2 * (n >> 6) + 64, dtype=torch.int16, device=dev)
+            h.set_stream(stream)
+            return h, (lambda: h.decimate_dev(x.data_ptr(), 2 * n, out.data_ptr())), [h, out]
+        per = (n // S) & ~1023
+        hs = [sa.Decimators(6, sa.FC_CEN, 12, device=dev.index) for _ in range(S)]
+        hs[0].set_stream(stream)
+        outs = [torch.empty(2 * (per >> 6) + 64, dtype=torch.int16, device=dev) for _ in range(S)]
+        ins = [x.data_ptr() + 4 * per * i for i in range(S)]
+        optr = [o.data_ptr() for o in outs]
+        cnt = [2 * per] * S
+        return hs[0], (lambda: sa.decimate_dev_batch(hs, ins, cnt, optr)), [hs, outs]
+
+    def make_bank(n_ch, kind):
+        fcs = chan_centres(n_ch, kind)
+        b = sa.ChannelizerBank(61_440_000, [48000] * n_ch, fcs, device=dev.index)
+        b.set_stream(stream)
+        return b, fcs
+
+    be = None
+    fcs = None
+    if wl == "fi64":
         # SURVEY 8f.4: DecimatorsFI::decimate64_cen (AirspyHF thread), float I/Q in, int16 Samples out
         xf = (x[: 2 * B].to(torch.float32) / 4096.0).contiguous()
         del x
@@ -246,117 +399,163 @@ def main():
         out = torch.empty(2 * (B >> 6) + 64, dtype=torch.int16, device=dev)
         h.set_stream(stream)
         step = lambda: h.decimate_dev(x.data_ptr(), 2 * B, out.data_ptr())
-        bytes_per_sample = 8.0 + 4.0 / 64
+        timed_handles["fdecim"] = (h, 8.0 + 4.0 / 64, None)
         workload = f"8f.4: DecimatorsFI::decimate64_cen (IntHalfbandFilterEOF<64> x 6), one stream per GPU, {B} complex float32 samples per step, device-resident"
-    elif args.workload == "decim64":
-        h = sa.Decimators(6, sa.FC_CEN, 12, device=dev.index)
-        out = torch.empty(2 * (B >> 6) + 64, dtype=torch.int16, device=dev)
-        h.set_stream(stream)
-        step = lambda: h.decimate_dev(x.data_ptr(), 2 * B, out.data_ptr())
-        bytes_per_sample = 4.0 + 4.0 / 64
-        workload = f"cfg2: decimate64_cen Decimators<qint32,qint16,16,12>, one stream per GPU, {B} complex int16 samples per step, device-resident"
+    elif wl == "decim64":
+        h, step, _keep = make_decim(B)
+        timed_handles["decim64"] = (h, 4.0 + 4.0 / 64, 32.5)
+        workload = f"cfg2: decimate64_cen Decimators<qint32,qint16,16,12>, {S} stream(s) per GPU in one launch, {B} complex int16 samples per step, device-resident"
+    elif wl == "headline":
+        h, dstep, _keep = make_decim(B)
+        bank, fcs = make_bank(32, "chan32")
+        def step():
+            dstep()
+            bank.feed_dev(x.data_ptr(), B)
+            for c in range(32):               # consumer side: drop the queued outputs (host bookkeeping only)
+                bank.skip(c)
+        bps_b, d2_b = bank_figures(bank, 32)
+        timed_handles["decim64"] = (h, 4.0 + 4.0 / 64, 32.5)
+        timed_handles["chan32"] = (bank, bps_b, d2_b)
+        workload = (f"cfg2 + cfg3 over the same resident batch: decimate64_cen Decimators<qint32,qint16,16,12> ({S} stream(s), one launch) and the 32-channel "
+                    f"DownChannelizer bank (48 kS/s channels from a 61.44 MS/s-shaped stream), {B} complex int16 samples per step and GPU")
     else:
-        # SURVEY.md §8(d): cfg 3 = 32 channels, cfg 5 = 128 channels per stream/GPU, cfg 4 = 256 channels + demod front
-        n_ch = {"chan32": 32, "chan128": 128, "cfg4": 256}[args.workload]
-        k = torch.arange(n_ch, dtype=torch.float64)
-        if args.workload == "cfg4":
-            fcs = (-25_000_000 + k * (50_000_000 / 255)).to(torch.int64).tolist()
-        else:
-            fcs = (-15_000_000 + k * (30_000_000 / (n_ch - 1)) + 137 * k).to(torch.int64).tolist()
-        h = sa.ChannelizerBank(61_440_000, [48000] * n_ch, fcs, device=dev.index)
-        h.set_stream(stream)
-        be = None
-        if args.workload == "cfg4":
+        # SURVEY.md 8(d): cfg 3 = 32 channels, cfg 5 = 128 channels per stream/GPU, cfg 4 = 256 channels + demod front
+        n_ch = {"chan32": 32, "chan128": 128, "cfg4": 256}[wl]
+        bank, fcs = make_bank(n_ch, wl)
+        if wl == "cfg4":
             cfgs = []
             for c in range(n_ch):
-                _m, out_rate, ofs = h.info(c)
+                _m, out_rate, ofs = bank.info(c)
                 cfgs.append(sa.BackendCfg(in_rate=out_rate, nco_freq=-ofs, out_rate=48000, interp_cutoff=12500 / 2.2, taps_per_phase=4.5,
                                           filt_mode=2, f1=300 / 48000, f2=5000 / 48000, discri=1, fm_scaling=48000 / 2000))
             be = sa.BackendBank(cfgs, device=dev.index)
         def step():
-            h.feed_dev(x.data_ptr(), B)
+            bank.feed_dev(x.data_ptr(), B)
             if be is not None:
-                be.feed_bank(h)                  # device-ordered hand-over; the back-end runs on its own stream
+                be.feed_bank(bank)               # device-ordered hand-over; the back-end runs on its own stream
                 if not os.environ.get("SDRX_BENCH_CFG4_PIPELINED"):
                     be.sync()                    # letting the back-end overlap the NEXT step's channelizer measured slower (2.97 vs 2.40 ms/step)
-            for c in range(n_ch):               # consumer side: drop the queued outputs (host bookkeeping only)
-                h.skip(c)
-        depth = sum(4.0 / (1 << len(h.info(c)[0])) for c in range(n_ch))
-        bytes_per_sample = 4.0 + depth + (n_ch * 4.0 * 48000 / 61_440_000 if be is not None else 0.0)
-        workload = (f"{args.workload}: DownChannelizer bank, {n_ch} channels (48 kS/s each) from one 61.44 MS/s-shaped stream per GPU"
+            for c in range(n_ch):
+                bank.skip(c)
+        bps_b, d2_b = bank_figures(bank, n_ch)
+        if be is not None:
+            bps_b += n_ch * 4.0 * 48000 / 61_440_000
+        timed_handles[wl] = (bank, bps_b, d2_b)
+        workload = (f"{wl}: DownChannelizer bank, {n_ch} channels (48 kS/s each) from one 61.44 MS/s-shaped stream per GPU"
                     + (" + NCO/Interpolator/fftfilt-SSB/NFM-discriminator front per channel" if be is not None else "")
                     + f", {B} samples per step")
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
-    h.set_timing(True)
-    elapsed = shard.timed_region(step, args.steps, 0, lambda: torch.cuda.synchronize(dev), dist=dist, device=dev if backend != "gloo" else None)
-    k_ms, k_n = h.get_timing()
-    h.set_timing(False)
+    for hh, _b, _d in timed_handles.values():
+        hh.set_timing(True)
+    sync = (lambda: (be.sync(), torch.cuda.synchronize(dev))) if be is not None else (lambda: torch.cuda.synchronize(dev))
+    elapsed = shard.timed_region(step, args.steps, 0, sync, dist=dist, device=red_dev)
+    per_kernel = {}
+    for name, (hh, bps, d2) in timed_handles.items():
+        k_ms, k_n = hh.get_timing()
+        hh.set_timing(False)
+        ll = hh.last_launch()
+        per_feed = k_ms / max(args.steps, 1)                 # a bank feed is several tree_kernel launches: per step
+        ach = bps * B / (per_feed * 1e-3) / 1e9
+        e = {"kernel": ll["kernel"] + (" (all passes of a feed)" if "tree" in ll["kernel"] else ""), "kernel_ms": round(per_feed, 4),
+             "launches": k_n, "algorithmic_bytes_per_sample": round(bps, 4), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+             "grid": ll["grid"], "block": ll["block"], "lds_bytes": ll["lds_bytes"]}
+        if d2:
+            e["dot2_per_sample"] = round(d2, 2)
+            e["valu_ceiling_frac"] = round(DOT2_PER_S / d2 * bps / 1e9 / HBM_PEAK_GBS, 4)
+        tr, src = load_traffic(ll["kernel"], B, name)
+        e["traffic"] = tr; e["traffic_source"] = src
+        per_kernel[name] = e
+
+    # cfg 5's per-GPU share, every rank, same protocol (also at N = 1 so the driver's per-N lines give its curve too)
+    also = {}
+    if wl == "headline" and not args.no_also:
+        nb = min(B, 1 << 28)
+        b128, _f = make_bank(128, "chan128")
+        def s128():
+            b128.feed_dev(x.data_ptr(), nb)
+            for c in range(128):
+                b128.skip(c)
+        for _ in range(2):
+            s128()
+        torch.cuda.synchronize(dev)
+        b128.set_timing(True)
+        el128 = shard.timed_region(s128, 5, 0, lambda: torch.cuda.synchronize(dev), dist=dist, device=red_dev)
+        ms128, _n = b128.get_timing(); b128.set_timing(False)
+        bps128, d2_128 = bank_figures(b128, 128)
+        also["chan128"] = {"workload": f"cfg5 per GPU: DownChannelizer bank, 128 channels x 48 kS/s from one 61.44 MS/s-shaped stream per GPU, {nb} samples per feed",
+                           "value": round(n_gpus * 5 * nb / el128 / 1e6, 1), "unit": "MS/s", "n_gpus": n_gpus, "kernel": "tree_kernel (all passes of a feed)",
+                           "kernel_ms": round(ms128 / 5, 4), "algorithmic_bytes_per_sample": round(bps128, 4),
+                           "roofline_frac": round(bps128 * nb / (ms128 / 5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "valu_ceiling_frac": round(DOT2_PER_S / d2_128 * bps128 / 1e9 / HBM_PEAK_GBS, 4)}
+        del b128
 
     if rank == 0:
         value = n_gpus * args.steps * B / elapsed / 1e6
-        kern_ms = k_ms / max(k_n, 1)
-        achieved = bytes_per_sample * B / (kern_ms * 1e-3) / 1e9
-        ll = h.last_launch()
+        ms_step = elapsed / args.steps * 1e3
+        dom = max(per_kernel.values(), key=lambda e: e["kernel_ms"])
+        low = min(per_kernel.values(), key=lambda e: e["frac"])
+        roof = {"bound": "valu" if wl != "fi64" else "lds+valu", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": low["frac"], "traffic": dom["traffic"], "traffic_source": dom["traffic_source"],
+                "kernel": dom["kernel"], "kernel_ms": dom["kernel_ms"], "launches": dom["launches"],
+                "algorithmic_bytes_per_sample": dom["algorithmic_bytes_per_sample"],
+                "grid": dom["grid"], "block": dom["block"], "lds_bytes": dom["lds_bytes"],
+                "bound_evidence": "profiles/: SQ counters (VALU issue + power-limited clock), not HBM",
+                "per_kernel": per_kernel}
+        if "valu_ceiling_frac" in dom:
+            roof["valu_ceiling_frac"] = dom["valu_ceiling_frac"]
+        if wl == "cfg4":
+            # the step is tree passes + schedule/mix/FIR/FFT/finish of the back-end: the fraction is over the WHOLE step
+            whole = per_kernel[wl]["algorithmic_bytes_per_sample"] * B / (ms_step * 1e-3) / 1e9
+            roof["tree_ms"] = dom["kernel_ms"]; roof["backend_ms"] = round(ms_step - dom["kernel_ms"], 4)
+            roof["achieved"] = round(whole, 1); roof["frac"] = round(whole / HBM_PEAK_GBS, 4)
+            roof["kernel"] = "whole step: tree_kernel passes + be_schedule/mix/fir/fft/finish"; roof["kernel_ms"] = round(ms_step, 4)
         line = {
-            "metric": "MS/s complex int16 IQ through decim-64 + DownChannelizer, 1/2/4/8 GPU; % HBM roofline",
+            "metric": METRIC,
             "value": round(value, 1), "unit": "MS/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.workload == "fi64" else "int32", "data": "synthetic",
-            "config": {"workload": workload, "streams": n_gpus, "parallelism": f"{n_gpus} independent stream(s), one per GPU, no collective"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": load_traffic(ll["kernel"], B, args.workload),
-                         "kernel": ll["kernel"], "kernel_ms": round(kern_ms, 4), "launches": k_n,
-                         "algorithmic_bytes_per_sample": bytes_per_sample,
-                         "grid": ll["grid"], "block": ll["block"], "lds_bytes": ll["lds_bytes"]},
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if wl == "fi64" else "int32", "data": "synthetic",
+            "config": {"workload": workload, "streams": n_gpus * (S if wl in ("headline", "decim64") else 1), "streams_per_gpu": S if wl in ("headline", "decim64") else 1,
+                       "parallelism": f"{n_gpus} GPU(s), one independent 61.44 MS/s-shaped stream set per GPU, no collective"
+                                      + (" [REHEARSAL: ranks share GPUs, gloo rendezvous]" if rehearsal else "")},
+            "roofline": roof,
         }
-        if n_gpus == 1 and args.workload == "decim64" and not args.no_also:
-            # the other half of the metric's name: BASELINE configs[2], 32-channel DownChannelizer bank, same GPU, same run
-            nb = B                                         # the same resident buffer
-            k32 = torch.arange(32, dtype=torch.float64)
-            fcs32 = (-15_000_000 + k32 * (30_000_000 / 31) + 137 * k32).to(torch.int64).tolist()
-            bank = sa.ChannelizerBank(61_440_000, [48000] * 32, fcs32, device=dev.index)
-            bank.set_stream(stream)
-            def bstep():
-                bank.feed_dev(x.data_ptr(), nb)
-                for c in range(32):
-                    bank.skip(c)
-            for _ in range(2):
-                bstep()
-            torch.cuda.synchronize(dev)
-            bank.set_timing(True)
-            t0 = time.perf_counter()
-            for _ in range(5):
-                bstep()
-            torch.cuda.synchronize(dev)
-            bel = time.perf_counter() - t0
-            bms, bn = bank.get_timing()
-            bms /= max(bn, 1)
-            bps = 4.0 + 32 * 4.0 / 1024
-            line["also"] = {"chan32": {"workload": "cfg3: DownChannelizer bank, 32 channels x 48 kS/s from one 61.44 MS/s-shaped stream, %d samples per feed" % nb,
-                                       "value": round(5 * nb / bel / 1e6, 1), "unit": "MS/s", "kernel": "tree_kernel (all passes of a feed)",
-                                       "kernel_ms": round(bms, 4), "algorithmic_bytes_per_sample": bps,
-                                       "roofline_frac": round(bps * nb / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
-            del bank
+        if also:
+            line["also"] = also
         if n_gpus == 1:
             # the denominator twice -- datasheet (peak/frac above) and a read-only streaming kernel on this box
             del x
             torch.cuda.empty_cache()
             meas = sa.measure_hbm_read(dev.index, 4 << 30, 5)
-            line["roofline"]["peak_measured"] = round(meas, 1)
-            line["roofline"]["frac_of_measured"] = round(achieved / meas, 4)
+            roof["peak_measured"] = round(meas, 1)
+            roof["frac_of_measured"] = round(roof["frac"] * HBM_PEAK_GBS / meas, 4)
         if n_gpus == 1 and not args.no_cpu:
-            if args.workload == "fi64":
-                line["cpu_baseline"] = cpu_baseline_fi(4 * 1024 * 1024, 8)
-            elif args.workload == "decim64":
-                line["cpu_baseline"] = cpu_baseline(8 * 1024 * 1024, 16)
+            nt = host_threads()
+            host = {"cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(), "threads_used": nt}
+            if wl == "fi64":
+                cb = cpu_fi(4 * 1024 * 1024, 8, nt)
+            elif wl == "decim64":
+                cb = cpu_decim(6, 8 * 1024 * 1024, 8, nt)
+            elif wl == "headline":
+                d = cpu_decim(6, 8 * 1024 * 1024, 6, nt)
+                c = cpu_chan(fcs, 12 * 1024 * 1024, nt)
+                both = 1.0 / (1.0 / d["value"] + 1.0 / c["value"])
+                cb = {"value": round(both, 3), "unit": "MS/s", "cores": nt, "kind": d["kind"], "lib": d["lib"],
+                      "sample": "the step's two halves on the host cores: decim64 (" + d["sample"] + ") and chan32 (" + c["sample"]
+                                + "); value = samples/s through both = 1 / (1/decim64 + 1/chan32)",
+                      "decim64": d, "chan32": c}
             else:
-                line["cpu_baseline"] = cpu_baseline_chan(fcs, 4 * 1024 * 1024)
+                cb = cpu_chan(fcs, (4 if wl == "chan32" else 1) * 1024 * 1024, nt)
+            if wl in ("headline", "decim64"):
+                # BASELINE.json configs[0]: sdrangelbench -t decimateii -l 4 -n 10000000 -r 10 (sdrbench/mainbench.cpp:69-110)
+                cb["sdrbench_decim16"] = cpu_decim(4, 10_000_000, 10, nt, seed=5489)
+            cb["host"] = host
+            line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

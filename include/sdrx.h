@@ -75,6 +75,17 @@ int sdrx_decim_process(sdrx_decim_t* h, const int16_t* iq, int32_t n_int16,
  * d_iq must be 16-byte aligned. */
 int sdrx_decim_process_dev(sdrx_decim_t* h, const int16_t* d_iq, int64_t n_int16,
                            int16_t* d_out_iq, int64_t* n_out_cplx);
+/* MANY device streams, ONE launch.  The reference runs one Decimators object per device thread
+ * (plugins/samplesource/limesdrinput/limesdrinputthread.cpp:103-135, filesource/testsource likewise); with many
+ * concurrent device sets each of their blocks (32 768 samples for LimeSDR) is far too small to fill a GPU on its own.
+ * handles[i] consumes n_elems[i] input elements at d_iq[i] (int16 for sdrx_decim_create handles, bytes for
+ * sdrx_decim_create_u8 ones; same whole-group / tail-drop rule per stream, each stream's own carried state) into
+ * d_out_iq[i]; n_out_cplx[i] (optional) receives how far that stream's `it` advanced.  All handles must have been created
+ * with the same (log2, fcpos, input flavour) on the same device and must be distinct; everything is queued on
+ * handles[0]'s stream, which the other handles join (as by sdrx_decim_set_stream) the first time.  More than 64
+ * handles are served by consecutive launches of 64. */
+int sdrx_decim_process_dev_batch(sdrx_decim_t* const* handles, int32_t n_handles, const void* const* d_iq,
+                                 const int64_t* n_elems, int16_t* const* d_out_iq, int64_t* n_out_cplx);
 int sdrx_decim_sync(sdrx_decim_t* h);
 /* run on a caller-owned hipStream_t; NULL = the handle's own (non-blocking) stream.  The HIP default stream has the
  * handle value 0 and is therefore NOT selectable: work queued on it (PyTorch's default stream) is not ordered against the

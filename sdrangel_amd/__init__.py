@@ -65,6 +65,7 @@ def lib() -> C.CDLL:
         "sdrx_decim_reset": (C.c_int, [vp]),
         "sdrx_decim_process": (C.c_int, [vp, vp, i32, vp, C.POINTER(i32)]),
         "sdrx_decim_process_dev": (C.c_int, [vp, vp, i64, vp, C.POINTER(i64)]),
+        "sdrx_decim_process_dev_batch": (C.c_int, [vp, i32, vp, vp, vp, vp]),
         "sdrx_decim_sync": (C.c_int, [vp]),
         "sdrx_decim_set_stream": (C.c_int, [vp, vp]),
         "sdrx_decim_group_int16": (C.c_int, [C.c_int, C.c_int]),
@@ -230,6 +231,21 @@ class Decimators:
         g, b, l = C.c_int(), C.c_int(), C.c_int()
         _check(lib().sdrx_decim_last_launch(self._h, name, 128, C.byref(g), C.byref(b), C.byref(l)), "last_launch")
         return {"kernel": name.value.decode(), "grid": g.value, "block": b.value, "lds_bytes": l.value}
+
+
+def decimate_dev_batch(handles, d_in_ptrs, n_elems, d_out_ptrs) -> list:
+    """sdrx_decim_process_dev_batch: many device streams (one Decimators / DecimatorsU object each, same configuration),
+    one launch.  Device pointers; asynchronous on handles[0]'s stream; returns #complex outputs per stream."""
+    n = len(handles)
+    if not (n == len(d_in_ptrs) == len(n_elems) == len(d_out_ptrs)):
+        raise ValueError("one pointer / count per handle")
+    hs = (C.c_void_p * n)(*[h._h.value for h in handles])
+    ins = (C.c_void_p * n)(*d_in_ptrs)
+    outs = (C.c_void_p * n)(*d_out_ptrs)
+    ns = (C.c_int64 * n)(*n_elems)
+    no = (C.c_int64 * n)()
+    _check(lib().sdrx_decim_process_dev_batch(hs, n, ins, ns, outs, no), "sdrx_decim_process_dev_batch")
+    return list(no)
 
 
 class DecimatorsU(Decimators):

@@ -185,14 +185,16 @@ __host__ __device__ constexpr int df_lds_dwords(int L) { return df_off(L + 1); }
 
 template<int L, int FC, int PRE, bool U8>
 __global__ __launch_bounds__(64)
-void decim_fast_kernel(const void* __restrict__ hist_v,    // DF_CHUNK samples: tail of the previous call
-                       const void* __restrict__ in_v, uint32_t* __restrict__ out,
-                       uint32_t* __restrict__ ovf_flags,   // one per DF_CHUNK-sample chunk of this call
-                       long n_in, int n_sub, int spw, int post, int in_shift)
+void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
 {
     typedef typename Quad<U8>::T QT;
-    const QT* __restrict__ hist = static_cast<const QT*>(hist_v);
-    const QT* __restrict__ in = static_cast<const QT*>(in_v);
+    const DecimJob& job = jobs.j[blockIdx.y];              // blockIdx.y = device stream; scalar loads from the kernarg segment
+    const QT* __restrict__ hist = static_cast<const QT*>(job.hist);
+    const QT* __restrict__ in = static_cast<const QT*>(job.in);
+    uint32_t* __restrict__ out = job.out;
+    uint32_t* __restrict__ ovf_flags = job.flags;          // one per DF_CHUNK-sample chunk of this call
+    const long n_in = job.n_in;
+    const int n_sub = job.n_units;
     constexpr int S = DF_SUB, LPT = S / 4 / 64;            // 4 uint4 per lane per sub-chunk
     __shared__ __attribute__((aligned(16))) uint32_t lds[df_lds_dwords(L)];
     const int lane = threadIdx.x;

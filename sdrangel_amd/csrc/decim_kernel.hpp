@@ -22,6 +22,20 @@ namespace sdrx {
 constexpr int DC_CHUNK = 4096;       // input samples per chunk
 constexpr int DC_THREADS = 256;
 
+// One launch serves up to DJ_MAX independent device streams (blockIdx.y = stream): the per-stream arguments travel
+// as a by-value table in the kernarg segment (scalar loads, no extra copy or allocation per call).
+constexpr int DJ_MAX = 64;
+struct DecimJob {
+    const void* hist;                // DC_CHUNK samples: tail of this stream's previous call
+    const void* in;                  // n_in samples (quad aligned)
+    uint32_t*   out;                 // n_in >> L packed Samples
+    uint32_t*   flags;               // one per DC_CHUNK-sample chunk (FAST kernel writes, EXACT kernel reads; nullptr: recompute all)
+    long        n_in;
+    int         n_units;             // sub-chunks (FAST) or chunks (EXACT) of this stream
+    int         pad_;
+};
+struct DecimJobs { DecimJob j[DJ_MAX]; };
+
 // outputs per lane of stage s (1-based) -- chosen so that the first three stages keep all 256
 // lanes busy (2048/8, 1024/4, 512/2) and the low-rate tail still uses >= 32 lanes.
 __host__ __device__ constexpr int dc_R(int s) { return s == 1 ? 8 : s == 2 ? 4 : 2; }
@@ -61,15 +75,16 @@ __host__ __device__ constexpr int dc_mode(int L, int fc, int s)
 
 template<int L, int FC, int PRE, bool U8>
 __global__ __launch_bounds__(DC_THREADS, 3)
-void decim_chain_kernel(const void* __restrict__ hist_v,  // DC_CHUNK samples: tail of the previous call
-                        const void* __restrict__ in_v,    // n_in samples (quad aligned)
-                        uint32_t* __restrict__ out,       // n_in >> L packed Samples
-                        const uint32_t* __restrict__ flags, // per chunk: recompute? (nullptr: all) -- set by the FAST kernel
-                        long n_in, int n_chunks, int cps, int post, int in_shift)
+void decim_chain_kernel(const DecimJobs jobs, int cps, int post, int in_shift)
 {
     typedef typename Quad<U8>::T QT;
-    const QT* __restrict__ hist = static_cast<const QT*>(hist_v);
-    const QT* __restrict__ in = static_cast<const QT*>(in_v);
+    const DecimJob& job = jobs.j[blockIdx.y];             // wave-uniform: scalar loads from the kernarg segment
+    const QT* __restrict__ hist = static_cast<const QT*>(job.hist);
+    const QT* __restrict__ in = static_cast<const QT*>(job.in);
+    uint32_t* __restrict__ out = job.out;
+    const uint32_t* __restrict__ flags = job.flags;       // per chunk: recompute? (nullptr: all) -- set by the FAST kernel
+    const long n_in = job.n_in;
+    const int n_chunks = job.n_units;
     constexpr int C = DC_CHUNK, NT = DC_THREADS;
     constexpr int LPT = C / 4 / NT;                       // uint4 loads per lane per chunk (4)
     __shared__ __attribute__((aligned(16))) uint32_t lds[dc_lds_dwords(L)];

@@ -4,6 +4,7 @@
 #include "decim_kernel.hpp"
 #include "decim_fast_kernel.hpp"
 #include <cstring>
+#include <utility>
 #include <cstdlib>
 #include <new>
 
@@ -29,18 +30,20 @@ __global__ void decim1_u8_kernel(const uint16_t* __restrict__ in, uint32_t* __re
     }
 }
 
-// new history = last `hist_dw` dwords of (old history ++ consumed input), all counted in dwords
-__global__ void hist_update_kernel(const uint32_t* __restrict__ old_hist, const uint32_t* __restrict__ in,
-                                   uint32_t* __restrict__ new_hist, long n_in_dw, int hist_dw)
+// new history = last `hist_dw` dwords of (old history ++ consumed input), all counted in dwords; blockIdx.y = stream
+struct HistJob { const uint32_t* old_hist; const uint32_t* in; uint32_t* new_hist; long n_in_dw; };
+struct HistJobs { HistJob j[DJ_MAX]; };
+__global__ void hist_update_kernel(const HistJobs jobs, int hist_dw)
 {
+    const HistJob& job = jobs.j[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= hist_dw) return;
-    const long src = (long)i + n_in_dw - hist_dw;
-    new_hist[i] = src >= 0 ? in[src] : old_hist[i + n_in_dw];
+    const long src = (long)i + job.n_in_dw - hist_dw;
+    job.new_hist[i] = src >= 0 ? job.in[src] : job.old_hist[i + job.n_in_dw];
 }
 
-typedef void (*chain_fn)(const void*, const void*, uint32_t*, const uint32_t*, long, int, int, int, int);
-typedef void (*fast_fn)(const void*, const void*, uint32_t*, uint32_t*, long, int, int, int, int);
+typedef void (*chain_fn)(const DecimJobs, int, int, int);
+typedef void (*fast_fn)(const DecimJobs, int, int, int);
 
 struct ChainEntry { chain_fn fn; fast_fn fast; const char* name; const char* fast_name; int lds; int fast_lds; };
 
@@ -138,74 +141,110 @@ static int choose_cps(long n_chunks, int slots)
     return (int)best;
 }
 
-static int launch(sdrx_decim* h, const void* d_iq, long n_cplx, int16_t* d_out)
+// One launch (per kernel) for n <= DJ_MAX streams of one configuration: hs[i] consumes n_cplx[i] whole-group samples
+// at d_iq[i] into d_out[i].  Everything is queued on hs[0]'s stream; timing and last_launch are kept on hs[0].
+static int launch_batch(sdrx_decim* const* hs, int n, const void* const* d_iq, const long* n_cplx, int16_t* const* d_out)
 {
-    // n_cplx: whole groups only (caller truncated)
-    if (n_cplx <= 0) return SDRX_OK;
+    sdrx_decim* h = hs[0];
+    long total = 0, longest = 0;
+    for (int i = 0; i < n; i++) { total += n_cplx[i]; if (n_cplx[i] > longest) longest = n_cplx[i]; }
+    if (total <= 0) return SDRX_OK;
     if (h->log2 == 0) {
-        const int block = 256;
-        long grid = (n_cplx + block - 1) / block; if (grid > 4096) grid = 4096;
-        if (h->u8)
-            hipLaunchKernelGGL(decim1_u8_kernel, dim3((unsigned)grid), dim3(block), 0, h->stream,
-                               static_cast<const uint16_t*>(d_iq), reinterpret_cast<uint32_t*>(d_out), n_cplx, h->pre, h->in_shift);
-        else
-            hipLaunchKernelGGL(decim1_kernel, dim3((unsigned)grid), dim3(block), 0, h->stream,
-                               static_cast<const uint32_t*>(d_iq), reinterpret_cast<uint32_t*>(d_out), n_cplx, h->pre);
-        SDRX_HIP(hipGetLastError());
-        snprintf(h->last_name, sizeof h->last_name, "decim1_kernel");
-        h->last_grid = (int)grid; h->last_block = block; h->last_lds = 0;
+        for (int i = 0; i < n; i++) {
+            if (n_cplx[i] <= 0) continue;
+            const int block = 256;
+            long grid = (n_cplx[i] + block - 1) / block; if (grid > 4096) grid = 4096;
+            if (h->u8)
+                hipLaunchKernelGGL(decim1_u8_kernel, dim3((unsigned)grid), dim3(block), 0, h->stream,
+                                   static_cast<const uint16_t*>(d_iq[i]), reinterpret_cast<uint32_t*>(d_out[i]), n_cplx[i], h->pre, h->in_shift);
+            else
+                hipLaunchKernelGGL(decim1_kernel, dim3((unsigned)grid), dim3(block), 0, h->stream,
+                                   static_cast<const uint32_t*>(d_iq[i]), reinterpret_cast<uint32_t*>(d_out[i]), n_cplx[i], h->pre);
+            SDRX_HIP(hipGetLastError());
+            snprintf(h->last_name, sizeof h->last_name, "decim1_kernel");
+            h->last_grid = (int)grid; h->last_block = block; h->last_lds = 0;
+        }
         return SDRX_OK;
     }
-    const long n_chunks = (n_cplx + DC_CHUNK - 1) / DC_CHUNK;
-    if (n_chunks > 0x7fffffffL / 4) { set_error("input too long for one call"); return SDRX_EINVAL; }
-    const void* hist = h->d_hist[h->cur];
-    const void* in4 = d_iq;
-    uint32_t* out = reinterpret_cast<uint32_t*>(d_out);
-    uint32_t* flags = nullptr;
+    const long max_chunks = (longest + DC_CHUNK - 1) / DC_CHUNK;
+    if (max_chunks > 0x7fffffffL / 4) { set_error("input too long for one call"); return SDRX_EINVAL; }
+    DecimJobs jobs;
+    std::memset(&jobs, 0, sizeof jobs);
+    for (int i = 0; i < n; i++) {
+        DecimJob& j = jobs.j[i];
+        j.hist = hs[i]->d_hist[hs[i]->cur]; j.in = d_iq[i]; j.out = reinterpret_cast<uint32_t*>(d_out[i]);
+        j.flags = nullptr; j.n_in = n_cplx[i] > 0 ? n_cplx[i] : 0; j.n_units = 0;
+    }
+    bool have_flags = false;
     int trc = h->timer.begin(h->stream); if (trc) return trc;
     if (h->path != 1) {
         // FAST: one wave per segment of `spw` sub-chunks (multiple of 4 = one flag chunk), 4 warm-up
-        trc = h->d_flags.reserve((size_t)n_chunks * 4); if (trc) return trc;
-        flags = static_cast<uint32_t*>(h->d_flags.p);
-        const long n_sub = (n_cplx + DF_SUB - 1) / DF_SUB;
+        long tot_sub = 0, max_sub = 0;
+        for (int i = 0; i < n; i++) {
+            const long chunks = (jobs.j[i].n_in + DC_CHUNK - 1) / DC_CHUNK;
+            trc = hs[i]->d_flags.reserve((size_t)(chunks > 0 ? chunks : 1) * 4); if (trc) return trc;
+            jobs.j[i].flags = static_cast<uint32_t*>(hs[i]->d_flags.p);
+            const long ns = (jobs.j[i].n_in + DF_SUB - 1) / DF_SUB;
+            jobs.j[i].n_units = (int)ns; tot_sub += ns; if (ns > max_sub) max_sub = ns;
+        }
+        have_flags = true;
         // segment length: 32 sub-chunks (12.5 % warm-up) measured best once that still gives >= 8 waves
-        // per CU (sweep in profiles/r01_decim_sweep.txt); shorter inputs trade warm-up against fill
+        // per CU (sweep in profiles/r01_decim_sweep.txt); shorter inputs trade warm-up against fill.  A batch is
+        // sized by the sub-chunks of ALL its streams: that is what fills the chip.
         const long slots = (long)h->cus * 8;
         long spw = 32; double best = 1e300;
         const char* env = getenv("SDRX_DECIM_SPW");
         if (env && atoi(env) >= 4) spw = (atoi(env) / 4) * 4;
-        else if (n_sub >= 8 * 32 * slots) spw = 64;           // long launches: halve the warm-up share (512 Mi samples: 429 vs 418 GS/s, 1 Gi: 494 vs 471)
-        else if (n_sub < 32 * slots) for (long c = 4; c <= 32; c += 4) {
-            const long segs = (n_sub + c - 1) / c, rounds = (segs + slots - 1) / slots;
+        else if (tot_sub >= 8 * 32 * slots) spw = 64;          // long launches: halve the warm-up share (512 Mi samples: 429 vs 418 GS/s, 1 Gi: 494 vs 471)
+        else if (tot_sub < 32 * slots) for (long c = 4; c <= 32; c += 4) {
+            long segs = 0;
+            for (int i = 0; i < n; i++) segs += (jobs.j[i].n_units + c - 1) / c;
+            const long rounds = (segs + slots - 1) / slots;
             const double cost = (double)(c + DF_WARM) * (double)rounds;
             if (cost < best - 1e-9) { best = cost; spw = c; }
         }
-        const long segs = (n_sub + spw - 1) / spw;
-        hipLaunchKernelGGL(h->k.fast, dim3((unsigned)segs), dim3(64), 0, h->stream,
-                           hist, in4, out, flags, n_cplx, (int)n_sub, (int)spw, h->post, h->in_shift);
+        if (spw > max_sub) spw = ((max_sub + 3) / 4) * 4;
+        const long segs = (max_sub + spw - 1) / spw;
+        hipLaunchKernelGGL(h->k.fast, dim3((unsigned)segs, (unsigned)n), dim3(64), 0, h->stream, jobs, (int)spw, h->post, h->in_shift);
         SDRX_HIP(hipGetLastError());
         snprintf(h->last_name, sizeof h->last_name, "%s", h->k.fast_name);
-        h->last_grid = (int)segs; h->last_block = 64; h->last_lds = h->k.fast_lds;
+        h->last_grid = (int)(segs * n); h->last_block = 64; h->last_lds = h->k.fast_lds;
     }
     if (h->path != 2) {
-        const int cps = choose_cps(n_chunks, h->cus * 3);
-        long segs = (n_chunks + cps - 1) / cps;
-        if (flags && segs > h->cus) segs = h->cus;       // fallback run: grid-stride scan of the flags
-        hipLaunchKernelGGL(h->k.fn, dim3((unsigned)segs), dim3(DC_THREADS), 0, h->stream,
-                           hist, in4, out, static_cast<const uint32_t*>(flags), n_cplx, (int)n_chunks, cps, h->post, h->in_shift);
+        for (int i = 0; i < n; i++) jobs.j[i].n_units = (int)((jobs.j[i].n_in + DC_CHUNK - 1) / DC_CHUNK);
+        const int per = h->cus * 3 / n > 0 ? h->cus * 3 / n : 1;
+        const int cps = choose_cps(max_chunks, per);
+        long segs = (max_chunks + cps - 1) / cps;
+        if (have_flags) {                                      // fallback run: grid-stride scan of the flags
+            const long cap = (h->cus + n - 1) / n;
+            if (segs > cap) segs = cap;
+        }
+        hipLaunchKernelGGL(h->k.fn, dim3((unsigned)segs, (unsigned)n), dim3(DC_THREADS), 0, h->stream, jobs, cps, h->post, h->in_shift);
         SDRX_HIP(hipGetLastError());
         if (h->path == 1) {
             snprintf(h->last_name, sizeof h->last_name, "%s", h->k.name);
-            h->last_grid = (int)segs; h->last_block = DC_THREADS; h->last_lds = h->k.lds;
+            h->last_grid = (int)(segs * n); h->last_block = DC_THREADS; h->last_lds = h->k.lds;
         }
     }
     trc = h->timer.end(h->stream); if (trc) return trc;
     const int hist_dw = DC_CHUNK * h->bps / 4;
-    hipLaunchKernelGGL(hist_update_kernel, dim3((unsigned)((hist_dw + 255) / 256)), dim3(256), 0, h->stream,
-                       h->d_hist[h->cur], static_cast<const uint32_t*>(d_iq), h->d_hist[h->cur ^ 1], n_cplx * h->bps / 4, hist_dw);
+    HistJobs hj;
+    std::memset(&hj, 0, sizeof hj);
+    for (int i = 0; i < n; i++) {
+        hj.j[i].old_hist = hs[i]->d_hist[hs[i]->cur]; hj.j[i].in = static_cast<const uint32_t*>(d_iq[i]);
+        hj.j[i].new_hist = hs[i]->d_hist[hs[i]->cur ^ 1]; hj.j[i].n_in_dw = jobs.j[i].n_in * h->bps / 4;
+    }
+    hipLaunchKernelGGL(hist_update_kernel, dim3((unsigned)((hist_dw + 255) / 256), (unsigned)n), dim3(256), 0, h->stream, hj, hist_dw);
     SDRX_HIP(hipGetLastError());
-    h->cur ^= 1;
+    for (int i = 0; i < n; i++) hs[i]->cur ^= 1;
     return SDRX_OK;
+}
+
+static int launch(sdrx_decim* h, const void* d_iq, long n_cplx, int16_t* d_out)
+{
+    // n_cplx: whole groups only (caller truncated)
+    if (n_cplx <= 0) return SDRX_OK;
+    return launch_batch(&h, 1, &d_iq, &n_cplx, &d_out);
 }
 
 extern "C" {
@@ -343,6 +382,52 @@ int sdrx_decim_process_dev(sdrx_decim_t* h, const int16_t* d_iq, int64_t n_int16
     const int64_t n_cplx = groups * (h->group / 2);
     if (n_out_cplx) *n_out_cplx = n_cplx >> h->log2;
     return launch(h, d_iq, (long)n_cplx, d_out_iq);
+}
+
+int sdrx_decim_process_dev_batch(sdrx_decim_t* const* handles, int32_t n_handles, const void* const* d_iq, const int64_t* n_int16,
+                                 int16_t* const* d_out_iq, int64_t* n_out_cplx)
+{
+    if (!handles || n_handles <= 0 || !d_iq || !n_int16 || !d_out_iq) { set_error("sdrx_decim_process_dev_batch: bad argument"); return SDRX_EINVAL; }
+    sdrx_decim* h0 = handles[0];
+    if (!h0) { set_error("sdrx_decim_process_dev_batch: null handle"); return SDRX_EINVAL; }
+    SDRX_HIP(hipSetDevice(h0->device));
+    for (int i = 0; i < n_handles; i++) {
+        sdrx_decim* h = handles[i];
+        if (!h || h->u8 != h0->u8 || h->device != h0->device || h->log2 != h0->log2 || h->fcpos != h0->fcpos || h->bits != h0->bits ||
+            h->in_shift != h0->in_shift || h->path != h0->path) {
+            set_error("sdrx_decim_process_dev_batch: all handles must share one configuration and device"); return SDRX_EINVAL;
+        }
+        for (int k = 0; k < i; k++) if (handles[k] == h) { set_error("sdrx_decim_process_dev_batch: a handle appears twice"); return SDRX_EINVAL; }
+        if (n_int16[i] < 0 || (n_int16[i] > 0 && (!d_iq[i] || !d_out_iq[i]))) { set_error("sdrx_decim_process_dev_batch: bad stream argument"); return SDRX_EINVAL; }
+        if ((reinterpret_cast<uintptr_t>(d_iq[i]) & (h0->u8 ? 7u : 15u)) || (reinterpret_cast<uintptr_t>(d_out_iq[i]) & 3u)) {
+            set_error("sdrx_decim_process_dev_batch: d_iq must be 16-byte aligned (8 for the u8 flavour)"); return SDRX_EINVAL;
+        }
+        if (h->stream != h0->stream) {                       // the batch runs on handles[0]'s stream: join it once
+            SDRX_HIP(hipStreamSynchronize(h->stream));
+            h->stream = h0->stream;
+        }
+    }
+    for (int base = 0; base < n_handles; base += DJ_MAX) {
+        const int n = n_handles - base < DJ_MAX ? n_handles - base : DJ_MAX;
+        const void* in[DJ_MAX]; long nc[DJ_MAX]; int16_t* out[DJ_MAX];
+        for (int i = 0; i < n; i++) {
+            const int64_t groups = n_int16[base + i] / h0->group;          // trailing partial group dropped, per stream
+            nc[i] = (long)(groups * (h0->group / 2));
+            in[i] = d_iq[base + i]; out[i] = d_out_iq[base + i];
+            if (n_out_cplx) n_out_cplx[base + i] = nc[i] >> h0->log2;
+        }
+        sdrx_decim* first = handles[base];
+        if (base) {                                          // later sub-batches: keep timing / last_launch on handles[0]
+            std::swap(first->timer, h0->timer);
+        }
+        const int rc = launch_batch(handles + base, n, in, nc, out);
+        if (base) {
+            std::swap(first->timer, h0->timer);
+            snprintf(h0->last_name, sizeof h0->last_name, "%s", first->last_name);
+        }
+        if (rc) return rc;
+    }
+    return SDRX_OK;
 }
 
 int sdrx_decim_process(sdrx_decim_t* h, const int16_t* iq, int32_t n_int16, int16_t* out_iq, int32_t* n_out_cplx)

@@ -68,6 +68,29 @@ def test_two_ranks_gloo_streams_shard_without_exchange():
     assert rate > 0
 
 
+@pytest.mark.timeout(180)
+def test_bench_launcher_spawns_n_ranks_and_rank0_prints_one_line():
+    """`python bench.py --gpus 2` with no torchrun around it: bench.py starts the ranks itself (before any HIP call),
+    they rendezvous (gloo here), and exactly one JSON line with n_gpus == 2 comes out."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["SDRX_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "launchcheck"],
+                       env=env, capture_output=True, text=True, timeout=150)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
+    # a rank count that contradicts the environment is refused, not silently ignored
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "launchcheck"], env=env2, capture_output=True, text=True, timeout=60)
+    assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)
+
+
 def test_stream_assignment_edges():
     assert shard.streams_of_rank(8, 3, 8) == [3]
     assert shard.streams_of_rank(3, 5, 8) == []                   # fewer streams than GPUs: idle rank ("replicas only" is bench's business)
