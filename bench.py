@@ -447,17 +447,33 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize(dev)
-    for hh, _b, _d in timed_handles.values():
-        hh.set_timing(True)
     sync = (lambda: (be.sync(), torch.cuda.synchronize(dev))) if be is not None else (lambda: torch.cuda.synchronize(dev))
+    sync()
     elapsed = shard.timed_region(step, args.steps, 0, sync, dist=dist, device=red_dev)
+
+    # per-kernel durations: HIP events recorded by the library on the launch stream (sdrx_*_get_timing).  With two
+    # different kernels queued back to back the start event of the second is stamped when the command processor reaches
+    # it, not when the first kernel has drained, so each part is timed in a pass of its own (same buffers, same sizes).
+    solo = {"decim64": (lambda: dstep()) if wl == "headline" else step, "fdecim": step}
+    if wl == "headline":
+        def bank_only():
+            bank.feed_dev(x.data_ptr(), B)
+            for c in range(32):
+                bank.skip(c)
+        solo["chan32"] = bank_only
     per_kernel = {}
+    n_solo = max(3, min(args.steps, 10))
     for name, (hh, bps, d2) in timed_handles.items():
+        fn = solo.get(name, step)
+        fn(); sync()
+        hh.set_timing(True)
+        for _ in range(n_solo):
+            fn()
+        sync()
         k_ms, k_n = hh.get_timing()
         hh.set_timing(False)
         ll = hh.last_launch()
-        per_feed = k_ms / max(args.steps, 1)                 # a bank feed is several tree_kernel launches: per step
+        per_feed = k_ms / n_solo                             # a bank feed is several tree_kernel launches: per step
         ach = bps * B / (per_feed * 1e-3) / 1e9
         e = {"kernel": ll["kernel"] + (" (all passes of a feed)" if "tree" in ll["kernel"] else ""), "kernel_ms": round(per_feed, 4),
              "launches": k_n, "algorithmic_bytes_per_sample": round(bps, 4), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),

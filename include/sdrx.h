@@ -130,6 +130,16 @@ int sdrx_chan_plan(int32_t in_rate, int32_t req_rate, int32_t req_fc,
 /* DSPConfigureChannelizer for one channel: chain rebuilt with ZERO history
  * (downchannelizer.cpp:167-171 frees and recreates the stages). */
 int sdrx_chan_bank_reconfigure(sdrx_chan_bank_t* h, int32_t ch, int32_t req_rate, int32_t req_fc);
+/* A new DownChannelizer next to the running ones (a demod plugin added to the device set,
+ * sdrbase/device/devicesourceapi.h:47-50 addThreadedSink): starts from zero history with the next feed; the existing
+ * channels keep their histories and queued output.  *channel = its index. */
+int sdrx_chan_bank_add_channel(sdrx_chan_bank_t* h, int32_t req_rate, int32_t req_fc, int32_t* channel);
+/* removeThreadedSink: channel `ch` stops producing and its queued output is dropped; the index stays reserved
+ * (it can be revived with sdrx_chan_bank_reconfigure). */
+int sdrx_chan_bank_remove_channel(sdrx_chan_bank_t* h, int32_t ch);
+/* number of independently planned stage tries the bank currently evaluates per feed (1 after create / reset; a
+ * reconfigured or added channel runs in a trie of its own, and tries without a live channel are retired) */
+int32_t sdrx_chan_bank_group_count(const sdrx_chan_bank_t* h);
 int sdrx_chan_bank_reset(sdrx_chan_bank_t* h);
 
 /* Replaces DownChannelizer::feed(begin, end, positiveOnly) for every channel of the bank.  Any

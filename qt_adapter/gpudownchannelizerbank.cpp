@@ -19,8 +19,21 @@ int GpuDownChannelizerBank::addChannel(BasebandSampleSink* demod)
 {
     Channel c; c.sink = demod; c.reqRate = 48000; c.reqFc = 0;
     m_channels.push_back(c);
-    rebuild();
-    return (int) m_channels.size() - 1;
+    const int index = (int) m_channels.size() - 1;
+    if (m_bank) {
+        // a DownChannelizer added next to running ones does not disturb them (DeviceSourceAPI::addThreadedSink):
+        // the bank grows by one chain that starts from zero history; the others keep history and queued output
+        int32_t got = -1;
+        if (sdrx_chan_bank_add_channel(m_bank, c.reqRate, c.reqFc, &got) != SDRX_OK || got != index) {
+            qCritical("GpuDownChannelizerBank::addChannel: %s", sdrx_last_error());
+            rebuild();
+        } else {
+            notify(index);
+        }
+    } else {
+        rebuild();                                                 // first channel, or no input rate yet
+    }
+    return index;
 }
 
 void GpuDownChannelizerBank::configureChannel(int channel, int sampleRate, int centerFrequency)

@@ -81,6 +81,9 @@ def lib() -> C.CDLL:
         "sdrx_chan_plan": (C.c_int, [i32, i32, i32, vp, C.POINTER(i32), C.POINTER(i32)]),
         "sdrx_chan_bank_reconfigure": (C.c_int, [vp, i32, i32, i32]),
         "sdrx_chan_bank_reset": (C.c_int, [vp]),
+        "sdrx_chan_bank_add_channel": (C.c_int, [vp, i32, i32, C.POINTER(i32)]),
+        "sdrx_chan_bank_remove_channel": (C.c_int, [vp, i32]),
+        "sdrx_chan_bank_group_count": (i32, [vp]),
         "sdrx_chan_bank_feed": (C.c_int, [vp, vp, i64]),
         "sdrx_chan_bank_feed_dev": (C.c_int, [vp, vp, i64]),
         "sdrx_chan_bank_available": (i64, [vp, i32]),
@@ -389,6 +392,19 @@ class ChannelizerBank:
         modes = np.zeros(32, np.uint8)
         _check(lib().sdrx_chan_bank_info(self._h, ch, C.byref(n), modes.ctypes.data, C.byref(r), C.byref(f)), "sdrx_chan_bank_info")
         return modes[: n.value].copy(), r.value, f.value
+
+    def add_channel(self, req_rate: int, req_fc: int) -> int:
+        c = C.c_int32(-1)
+        _check(lib().sdrx_chan_bank_add_channel(self._h, req_rate, req_fc, C.byref(c)), "sdrx_chan_bank_add_channel")
+        self.n_ch = max(getattr(self, "n_ch", 0), c.value + 1)
+        return c.value
+
+    def remove_channel(self, ch: int):
+        _check(lib().sdrx_chan_bank_remove_channel(self._h, ch), "sdrx_chan_bank_remove_channel")
+
+    @property
+    def group_count(self) -> int:
+        return lib().sdrx_chan_bank_group_count(self._h)
 
     def reconfigure(self, ch: int, req_rate: int, req_fc: int):
         _check(lib().sdrx_chan_bank_reconfigure(self._h, ch, req_rate, req_fc), "sdrx_chan_bank_reconfigure")

@@ -390,6 +390,28 @@ static int new_group(sdrx_chan_bank* b, const std::vector<int>& chans)
     return SDRX_OK;
 }
 
+// A group none of whose channels is live any more (every one reconfigured away or removed) is dropped: its kernels,
+// table uploads and device buffers would otherwise run / stay until reset.  Pending work on the stream may still read
+// the group's buffers, hence the synchronisation.  Groups behind it move down one slot.
+static int retire_dead_groups(sdrx_chan_bank* b)
+{
+    for (size_t gi = 0; gi < b->groups.size();) {
+        Group* g = b->groups[gi];
+        bool live = false;
+        for (int c : g->chans) if (b->ch[(size_t)c].group == g->index) { live = true; break; }
+        if (live) { gi++; continue; }
+        SDRX_HIP(hipStreamSynchronize(b->stream));
+        free_group(g);
+        b->groups.erase(b->groups.begin() + (long)gi);
+        for (size_t k = gi; k < b->groups.size(); k++) {
+            const int old = b->groups[k]->index;
+            b->groups[k]->index = (int)k;
+            for (int c : b->groups[k]->chans) if (b->ch[(size_t)c].group == old) b->ch[(size_t)c].group = (int)k;
+        }
+    }
+    return SDRX_OK;
+}
+
 // keep `used` bytes when growing a channel queue
 static int grow_keep(sdrx_chan_bank* b, DevBuf& buf, size_t used, size_t need)
 {
@@ -616,9 +638,40 @@ int sdrx_chan_bank_reconfigure(sdrx_chan_bank_t* b, int32_t c, int32_t req_rate,
     // (freeFilterChain + createFilterChain, downchannelizer.cpp:167-171)
     ch.group = -1;
     configure_channel(b, c, req_rate, req_fc);
+    // a group whose last live channel this was (typically the single-channel group of an earlier reconfigure) goes away;
+    // dead chains inside a group that still serves others keep being evaluated (shared prefixes) until the next reset
+    int rc = retire_dead_groups(b); if (rc) return rc;
     if (ch.passthrough) return SDRX_OK;
-    return new_group(b, std::vector<int>{ c });
+    return new_group(b, std::vector<int>{ (int)c });
 }
+
+int sdrx_chan_bank_add_channel(sdrx_chan_bank_t* b, int32_t req_rate, int32_t req_fc, int32_t* channel)
+{
+    if (!b) { set_error("sdrx_chan_bank_add_channel: null bank"); return SDRX_EINVAL; }
+    SDRX_HIP(hipSetDevice(b->device));
+    // a new DownChannelizer next to the existing ones: they keep their histories and queued output
+    b->ch.emplace_back();
+    const int c = (int)b->ch.size() - 1;
+    configure_channel(b, c, req_rate, req_fc);
+    if (channel) *channel = c;
+    if (b->ch[(size_t)c].passthrough) return SDRX_OK;
+    const int rc = new_group(b, std::vector<int>{ c });
+    if (rc) { b->ch.pop_back(); if (channel) *channel = -1; }
+    return rc;
+}
+
+int sdrx_chan_bank_remove_channel(sdrx_chan_bank_t* b, int32_t c)
+{
+    if (!b || c < 0 || c >= (int32_t)b->ch.size()) { set_error("sdrx_chan_bank_remove_channel: bad channel"); return SDRX_EINVAL; }
+    SDRX_HIP(hipSetDevice(b->device));
+    // the index stays reserved (other channels keep theirs); the chain stops producing and its queue is dropped
+    Channel& ch = b->ch[(size_t)c];
+    ch.group = -1; ch.passthrough = false; ch.n = 0; ch.out_rate = 0; ch.ofs = 0;
+    ch.avail = 0; ch.last_off = 0; ch.last_n = 0;
+    return retire_dead_groups(b);
+}
+
+int32_t sdrx_chan_bank_group_count(const sdrx_chan_bank_t* b) { return b ? (int32_t)b->groups.size() : SDRX_EINVAL; }
 
 int sdrx_chan_bank_reset(sdrx_chan_bank_t* b)
 {

@@ -123,3 +123,58 @@ def test_bank256_cfg4_shape_spot_check():
         m, r, o = bank.info(c)
         assert np.array_equal(m, modes) and (r, o) == (out_rate, ofs)
         assert np.array_equal(bank.read(c), orc.Chain(modes).feed(x)), c
+
+
+def test_retune_fifty_times_stays_exact_and_bounded():
+    """A live session retunes (DownChannelizer::configure per retune, downchannelizer.cpp:44-48): every reconfigure restarts
+    that channel from zero history; the bank must not accumulate dead stage tries (launches and device memory per feed
+    stay bounded) and the other channels must never notice."""
+    rates, fcs = cfg3_channels(6)
+    bank = sa.ChannelizerBank(FS, rates, fcs)
+    ref = oracle_bank(FS, rates, fcs)
+    assert bank.group_count == 1
+    n_blk = 40_000
+    x = orc.synth_iq(52 * n_blk, seed=1234, amp=2047, tone=(0.031, 800))
+    other = [[] for _ in ref]
+    for i in range(50):
+        seg = x[2 * i * n_blk: 2 * (i + 1) * n_blk]
+        fc_new = -20_000_000 + 777_001 * i
+        bank.reconfigure(2, 48000, fc_new)
+        assert bank.group_count <= 2, (i, bank.group_count)        # the original trie + channel 2's current one
+        modes, out_rate, ofs = orc.chan_plan(FS, 48000, fc_new)
+        m, r, o = bank.info(2)
+        assert np.array_equal(m, modes) and (r, o) == (out_rate, ofs)
+        bank.feed(seg)
+        assert np.array_equal(bank.read(2), orc.Chain(modes).feed(seg)), i     # a FRESH chain each time
+        for c in (0, 1, 3, 4, 5):
+            other[c].append(bank.read(c))
+    for c in (0, 1, 3, 4, 5):
+        assert np.array_equal(np.concatenate(other[c]), ref[c][0].feed(x[: 2 * 50 * n_blk])), c
+    # every original channel retuned once: the original trie has no live channel left and is retired
+    for c in (0, 1, 3, 4, 5):
+        bank.reconfigure(c, 48000, fcs[c] + 5000)
+    assert bank.group_count == 6
+
+
+def test_add_and_remove_channel_leave_the_others_alone():
+    rates, fcs = cfg3_channels(4)
+    bank = sa.ChannelizerBank(FS, rates, fcs)
+    ref = oracle_bank(FS, rates, fcs)
+    x = orc.synth_iq(300_000, seed=77, amp=2047, tone=(0.02, 900))
+    a, b = x[: 2 * 100_001], x[2 * 100_001:]
+    bank.feed(a)
+    c_new = bank.add_channel(48000, 7_654_321)                      # addThreadedSink on a running device set
+    assert c_new == 4 and bank.group_count == 2
+    modes, out_rate, ofs = orc.chan_plan(FS, 48000, 7_654_321)
+    assert (bank.info(4)[1], bank.info(4)[2]) == (out_rate, ofs)
+    bank.remove_channel(1)
+    bank.feed(b)
+    assert np.array_equal(bank.read(4), orc.Chain(modes).feed(b))   # starts at the first sample after it was added
+    assert bank.available(1) == 0
+    for c in (0, 2, 3):
+        assert np.array_equal(bank.read(c), ref[c][0].feed(x)), c   # history and queued output untouched
+    bank.remove_channel(4)
+    assert bank.group_count == 1
+    bank.reconfigure(1, 48000, fcs[1])                              # a removed index can be revived
+    bank.feed(a)
+    assert np.array_equal(bank.read(1), orc.Chain(ref[1][1]).feed(a))
