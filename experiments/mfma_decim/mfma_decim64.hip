@@ -1,0 +1,259 @@
+// EXPERIMENT -- NOT on the product path (libsdrx.so neither includes nor links this file).
+//
+// "Record one experiment -- stage 1 as a banded-Toeplitz MFMA ... with bit-exactness and
+// rate, outside the product path, so the conflict between north_star's 'no MFMA' and its '>= 80 %' can be adjudicated
+// on numbers rather than assertion."  This file goes one step further than stage 1: the WHOLE decimate64_cen chain of
+// Decimators<qint32,qint16,16,12> (sdrbase/dsp/decimators.h:3488-3885 over IntHalfbandFilterEO<qint32,qint32,64>::doFIR,
+// inthalfbandfiltereo.h:832-870) with every half-band FIR evaluated by v_mfma_f32_16x16x32_f16, bit-exact.
+//
+// Why f16 MFMA is EXACT here
+//   * taps are integers |h| <= 1300 < 2^11 and 2048: exactly representable in f16;
+//   * data is split into limbs x = xh * 2048 + xl, xl in [0, 2047], |xh| <= 2048: exactly representable in f16
+//     (stage 1: 12-bit contract samples need one limb only; checked, out-of-contract input raises the chunk's flag
+//     exactly like the product FAST kernel does for its int16 assumption);
+//   * every partial sum of a 32-tap row is an integer below 2^24 in magnitude (sum|h| * 2047 = 10.4 M), so the f32
+//     accumulation of the matrix core is exact in any association;
+//   * the centre tap needs no multiply at all:  (S + (e << 11)) >> 11  ==  e + floor(S / 2048);
+//   * y = floor(SL / 2048) + SH + e is again an exact f32 integer (< 2^22 for contract data through six stages).
+//
+// Structure (one 64-lane workgroup = one private pipeline, no barrier -- same decomposition as decim_fast_kernel.hpp):
+//   polyphase arms of every stage live in LDS as planar arrays with the FIR history in front: the odd arm as f16
+//   limb planes (lo, hi), the even arm (centre tap only) as f32.  A tile = 256 consecutive outputs:
+//       D[m][n] = sum_k A[m][k] * B[k][n],   B[k][n] = odd[base + 16 n + k]   (lane (n, q) reads ONE aligned ds_read_b128),
+//       A[m][k] = h[m + 32 - k]               (banded Toeplitz, built once per wave into 2 x 4 VGPRs),
+//   i.e. column n of the tile = outputs 16n .. 16n+15, 48 window slots = one K=32 MFMA + half of a second one.
+//   The D layout (lane (n, g) holds outputs 16n + 4g .. +3) is exactly "two odd + two even samples of the next stage",
+//   so the hand-over is two packed-f16 dword stores + two f32 stores per lane -- no cross-lane movement.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+namespace mfx {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int S = 1024;            // input samples per sub-chunk (one loop iteration of a wave)
+constexpr int WARM = 4;            // warm-up sub-chunks: 4096 >= 62 * 63 = the chain's memory
+constexpr int L = 6;               // decimate64
+constexpr int HO = 32;             // odd-arm history entries (31 needed; 32 keeps the windows 16-byte aligned)
+constexpr int HE = 15;             // even-arm history entries: output k reads e[k - 15]
+constexpr int CHUNK = 4096;        // flag granularity (== DC_CHUNK of the product kernels)
+
+__host__ __device__ constexpr int n_arm(int s) { return S >> s; }                       // entries per arm and sub-chunk = outputs of stage s
+__host__ __device__ constexpr int o_bytes(int s) { return (HO + n_arm(s)) * 2; }        // one f16 limb plane
+__host__ __device__ constexpr int e_bytes(int s) { return ((HE + n_arm(s)) * 4 + 15) / 16 * 16; }
+__host__ __device__ constexpr int n_limb(int s) { return s >= 2 ? 2 : 1; }
+__host__ __device__ constexpr int comp_bytes(int s) { return o_bytes(s) * n_limb(s) + e_bytes(s); }
+__host__ __device__ constexpr int stage_off(int s) { int o = 0; for (int u = 1; u < s; u++) o += 2 * comp_bytes(u); return o; }
+__host__ __device__ constexpr int fin_off() { return stage_off(L + 1); }                 // 2 x 16 f32: last stage's I / Q before packing
+__host__ __device__ constexpr int lds_total() { return fin_off() + 2 * 16 * 4; }
+
+__constant__ short k_c64[16] = { -1, 2, -5, 8, -12, 17, -25, 35, -47, 64, -86, 117, -164, 244, -424, 1300 };   // hbfiltertraits.cpp:136-154
+
+template<int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+__device__ __forceinline__ uint32_t pk_h2(float a, float b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));              // exact: both values are f16-representable integers
+}
+
+template<int POST>
+__global__ __launch_bounds__(64)
+void decim64_mfma_kernel(const uint4* __restrict__ hist,      // CHUNK samples: tail of the previous call
+                         const uint4* __restrict__ in, uint32_t* __restrict__ out,
+                         uint32_t* __restrict__ flags,        // one per CHUNK-sample chunk: 1 = input left the 12-bit contract
+                         long n_in, int n_sub, int spw)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[lds_total()];
+    const int lane = threadIdx.x, n = lane & 15, g = lane >> 4;
+    const long first = (long)blockIdx.x * spw;
+    if (first >= n_sub) return;
+    long last = first + spw; if (last > n_sub) last = n_sub;
+    const long n_in4 = n_in >> 2, n_out = n_in >> L;
+
+    for (int i = lane; i < lds_total() / 4; i += 64) reinterpret_cast<uint32_t*>(lds)[i] = 0;
+
+    // banded Toeplitz tap operands: row m = n (lane & 15), window slot kap = 8g + j (first MFMA) / 32 + 8g + j (second)
+    h8 Aa, Ab;
+    {
+        auto tap = [](int jj) -> _Float16 {
+            if (jj < 0 || jj > 31) return (_Float16)0.0f;
+            return (_Float16)(float)k_c64[jj < 16 ? jj : 31 - jj];
+        };
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            Aa[j] = tap(n + 32 - (8 * g + j));
+            Ab[j] = g < 2 ? tap(n + 32 - (32 + 8 * g + j)) : (_Float16)0.0f;           // lanes g >= 2: unused slots (their B data is a finite mirror)
+        }
+    }
+
+    uint4 pre[4];
+    auto fetch = [&](long sub) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const long q4 = sub * (S / 4) + j * 64 + lane;          // quad index; sub < 0: history
+            if (q4 < 0) pre[j] = hist[q4 + CHUNK / 4];
+            else pre[j] = q4 < n_in4 ? in[q4] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    fetch(first - WARM);
+    bool bad = false;
+    __syncthreads();
+
+    // byte offsets of a stage's arrays
+    auto oL = [](int s, int c) { return stage_off(s) + c * comp_bytes(s); };
+    auto eA = [](int s, int c) { return stage_off(s) + c * comp_bytes(s) + o_bytes(s) * n_limb(s); };
+
+    for (long sub = first - WARM; sub < last; ++sub) {
+        // ---- raw int16 I/Q -> stage-1 arms: odd arm as f16 (one limb: 12-bit contract), even arm as f32
+        uint32_t chk = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint4 v = pre[j];                                  // (I0,Q0) (I1,Q1) (I2,Q2) (I3,Q3)
+            const int quad = j * 64 + lane;
+            auto lo16 = [](uint32_t w) { return (float)(short)(w & 0xffffu); };
+            auto hi16 = [](uint32_t w) { return (float)(short)(w >> 16); };
+            *reinterpret_cast<uint32_t*>(lds + oL(1, 0) + (HO + 2 * quad) * 2) = pk_h2(lo16(v.y), lo16(v.w));
+            *reinterpret_cast<uint32_t*>(lds + oL(1, 1) + (HO + 2 * quad) * 2) = pk_h2(hi16(v.y), hi16(v.w));
+            float* e0 = reinterpret_cast<float*>(lds + eA(1, 0)) + HE + 2 * quad;
+            float* e1 = reinterpret_cast<float*>(lds + eA(1, 1)) + HE + 2 * quad;
+            e0[0] = lo16(v.x); e0[1] = lo16(v.z);
+            e1[0] = hi16(v.x); e1[1] = hi16(v.z);
+            // 12-bit contract check on all 8 int16: (x + 0x0800) must have no bit above 11, per half
+            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+            const us2 bias = { 0x0800, 0x0800 };
+            auto ck = [&](uint32_t w) { chk |= __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, w) + bias)); };
+            ck(v.x); ck(v.y); ck(v.z); ck(v.w);
+        }
+        if (sub + 1 < last) fetch(sub + 1);
+        if (!bad && __any((chk & 0xf000f000u) != 0)) bad = true;
+        __syncthreads();                                            // single-wave workgroup: a fence, no s_barrier
+
+        const bool live = sub >= first;
+        // ---- stages 1..6
+        static_for<1, L + 1>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr int NOUT = S >> s;                             // outputs per component and sub-chunk
+            constexpr bool MERGED = NOUT < 256;                      // I in columns [0, NC), Q in columns [8, 8 + NC): one tile for both
+            constexpr int NC = MERGED ? NOUT / 16 : 16;              // valid columns per component
+            constexpr int TILES = MERGED ? 1 : NOUT / 256;
+            constexpr int NCOMP = MERGED ? 1 : 2;
+            static_for<0, TILES * NCOMP>([&](auto tc) {
+                constexpr int t = decltype(tc)::value / NCOMP;
+                constexpr int cfix = decltype(tc)::value % NCOMP;
+                // component and column of this lane
+                const int comp = MERGED ? (n >> 3) : cfix;
+                const int col = MERGED ? (n & 7) : n;
+                const int colr = col < NC ? col : NC - 1;            // idle columns mirror a valid one (finite data, results dropped)
+                const bool valid = col < NC;
+                const int base = 256 * t + 16 * colr;                // arm index of window slot 0
+                const int cb = MERGED ? comp * comp_bytes(s) : 0;    // per-lane component select
+                const unsigned char* pl = lds + oL(s, MERGED ? 0 : cfix) + cb;
+                const h8 BaL = *reinterpret_cast<const h8*>(pl + (base + 8 * g) * 2);
+                const h8 BbL = *reinterpret_cast<const h8*>(pl + (base + 32 + 8 * (g & 1)) * 2);
+                f4 acc = { 0.f, 0.f, 0.f, 0.f };
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aa, BaL, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ab, BbL, acc, 0, 0, 0);
+                f4 acch = { 0.f, 0.f, 0.f, 0.f };
+                if constexpr (s >= 2) {
+                    const unsigned char* ph = pl + o_bytes(s);
+                    const h8 BaH = *reinterpret_cast<const h8*>(ph + (base + 8 * g) * 2);
+                    const h8 BbH = *reinterpret_cast<const h8*>(ph + (base + 32 + 8 * (g & 1)) * 2);
+                    acch = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aa, BaH, acch, 0, 0, 0);
+                    acch = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ab, BbH, acch, 0, 0, 0);
+                }
+                // centre tap: e[k - 15] for k = base + 4g + i  ->  even-arm entries (HE - 15) + base + 4g + i
+                const f4 ev = *reinterpret_cast<const f4*>(lds + eA(s, MERGED ? 0 : cfix) + cb + (base + 4 * g) * 4);
+                float y[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) y[i] = __builtin_floorf(acc[i] * 0x1p-11f) + acch[i] + ev[i];
+
+                if constexpr (s < L) {
+                    // lane (col, g) holds outputs k = 16 col + 4g + i: i = 1, 3 -> odd arm of stage s+1, i = 0, 2 -> even arm
+                    if (valid) {
+                        const int ko = 128 * t + 8 * col + 2 * g;                       // next-stage arm index of the pair
+                        constexpr int s2 = s + 1;
+                        const int cb2 = comp * comp_bytes(s2);
+                        const float h1 = __builtin_floorf(y[1] * 0x1p-11f), h3 = __builtin_floorf(y[3] * 0x1p-11f);
+                        const float l1 = __builtin_fmaf(h1, -2048.f, y[1]), l3 = __builtin_fmaf(h3, -2048.f, y[3]);
+                        unsigned char* po = lds + stage_off(s2) + cb2;
+                        *reinterpret_cast<uint32_t*>(po + (HO + ko) * 2) = pk_h2(l1, l3);
+                        *reinterpret_cast<uint32_t*>(po + o_bytes(s2) + (HO + ko) * 2) = pk_h2(h1, h3);
+                        float* pe = reinterpret_cast<float*>(po + o_bytes(s2) * 2) + HE + ko;
+                        pe[0] = y[0]; pe[1] = y[2];
+                    }
+                } else {
+                    // final stage (merged tile: I in column 0, Q in column 8): meet in LDS, then pack Samples
+                    if (valid) {
+                        f4 yv = { y[0], y[1], y[2], y[3] };
+                        *reinterpret_cast<f4*>(lds + fin_off() + comp * 64 + g * 16) = yv;
+                    }
+                }
+            });
+            __syncthreads();
+        });
+        if (live && lane < (S >> L)) {
+            const float yi = reinterpret_cast<const float*>(lds + fin_off())[lane];
+            const float yq = reinterpret_cast<const float*>(lds + fin_off() + 64)[lane];
+            const long k = sub * (S >> L) + lane;
+            if (k < n_out) {
+                const int re = (int)yi >> POST, im = (int)yq >> POST;
+                out[k] = ((uint32_t)re & 0xffffu) | ((uint32_t)im << 16);
+            }
+        }
+        if (live && lane == 0 && ((sub + 1) % (CHUNK / S) == 0 || sub + 1 == last))
+            flags[sub / (CHUNK / S)] = bad ? 1u : 0u;
+
+        // ---- carry: the last HO (HE) entries of every array become the next sub-chunk's history
+        static_for<1, L + 1>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr int NL = n_limb(s);
+            // per component: NL x 16 dwords (odd-arm limb planes) + 15 dwords (even arm); lanes 0..(16 NL + 14)
+            const int plane = lane >> 4, w = lane & 15;
+            const bool isE = plane == NL;
+            const bool act = plane < NL || (isE && w < HE);
+            const int src = isE ? o_bytes(s) * NL + (n_arm(s) + w) * 4 : plane * o_bytes(s) + n_arm(s) * 2 + w * 4;
+            const int dst = isE ? o_bytes(s) * NL + w * 4 : plane * o_bytes(s) + w * 4;
+            uint32_t v0 = 0, v1 = 0;
+            if (act) {
+                v0 = *reinterpret_cast<const uint32_t*>(lds + stage_off(s) + src);
+                v1 = *reinterpret_cast<const uint32_t*>(lds + stage_off(s) + comp_bytes(s) + src);
+            }
+            __syncthreads();
+            if (act) {
+                *reinterpret_cast<uint32_t*>(lds + stage_off(s) + dst) = v0;
+                *reinterpret_cast<uint32_t*>(lds + stage_off(s) + comp_bytes(s) + dst) = v1;
+            }
+        });
+        __syncthreads();
+    }
+}
+
+} // namespace mfx
+
+extern "C" {
+
+// d_hist: 4096 complex int16 samples (zeros for a fresh Decimators object), d_in: n_cplx samples (multiple of 64),
+// d_out: n_cplx / 64 packed Samples, d_flags: ceil(n_cplx / 4096) dwords.  post = decimation_shifts<16,12>::post64 = 2.
+// Asynchronous on `stream`.  Returns 0 or the hipError_t.
+int mfx_decim64(const void* d_hist, const void* d_in, void* d_out, uint32_t* d_flags, long n_cplx, int spw, void* stream)
+{
+    if (n_cplx <= 0) return 0;
+    const long n_sub = (n_cplx + mfx::S - 1) / mfx::S;
+    if (spw < 4) spw = 32;
+    const long segs = (n_sub + spw - 1) / spw;
+    hipLaunchKernelGGL(mfx::decim64_mfma_kernel<2>, dim3((unsigned)segs), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint4*>(d_hist), static_cast<const uint4*>(d_in), static_cast<uint32_t*>(d_out), d_flags,
+                       n_cplx, (int)n_sub, spw);
+    return (int)hipGetLastError();
+}
+
+int mfx_lds_bytes(void) { return mfx::lds_total(); }
+
+} // extern "C"
