@@ -31,6 +31,7 @@
 namespace mfx {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -43,7 +44,11 @@ constexpr int CHUNK = 4096;        // flag granularity (== DC_CHUNK of the produ
 
 __host__ __device__ constexpr int n_arm(int s) { return S >> s; }                       // entries per arm and sub-chunk = outputs of stage s
 __host__ __device__ constexpr int o_bytes(int s) { return (HO + n_arm(s)) * 2; }        // one f16 limb plane
-__host__ __device__ constexpr int e_bytes(int s) { return ((HE + n_arm(s)) * 4 + 15) / 16 * 16; }
+// physical position of even-arm entry i.  (Tried: 8 dwords of padding per 64 to spread the float4 reads over the banks --
+// SQ_LDS_BANK_CONFLICT did not move (6.9e7 vs 6.6e7 per 256 Mi samples: the counter mostly charges the extra beats of the
+// wide reads), and the larger arrays cost a wave per CU: 560 vs 603 GS/s.  Left as the identity.)
+__host__ __device__ constexpr int e_phys(int i) { return i; }
+__host__ __device__ constexpr int e_bytes(int s) { return (e_phys(HE + n_arm(s) - 1) + 1 + 3) / 4 * 16; }
 __host__ __device__ constexpr int n_limb(int s) { return s >= 2 ? 2 : 1; }
 __host__ __device__ constexpr int comp_bytes(int s) { return o_bytes(s) * n_limb(s) + e_bytes(s); }
 __host__ __device__ constexpr int stage_off(int s) { int o = 0; for (int u = 1; u < s; u++) o += 2 * comp_bytes(u); return o; }
@@ -110,128 +115,156 @@ void decim64_mfma_kernel(const uint4* __restrict__ hist,      // CHUNK samples: 
     auto oL = [](int s, int c) { return stage_off(s) + c * comp_bytes(s); };
     auto eA = [](int s, int c) { return stage_off(s) + c * comp_bytes(s) + o_bytes(s) * n_limb(s); };
 
-    for (long sub = first - WARM; sub < last; ++sub) {
-        // ---- raw int16 I/Q -> stage-1 arms: odd arm as f16 (one limb: 12-bit contract), even arm as f32
-        uint32_t chk = 0;
+    // Skewed pipeline: in iteration `it` stage s works on the data of sub-chunk it - (s - 1), and the stages run in
+    // REVERSE order (6 first).  Stage s reads only arrays written during the PREVIOUS iteration, so nothing inside an
+    // iteration depends on anything else inside it: one LDS/MFMA latency per iteration instead of six in a row.
+    // L - 1 extra iterations drain the pipe at the end of a segment (their stale results are never stored).
+    for (long it = first - WARM; it < last + (L - 1); ++it) {
+        // ---- raw int16 I/Q of sub-chunk `it` -> stage-1 arms: odd arm as f16 (one limb: 12-bit contract), even arm as f32
+        if (it < last) {
+            uint32_t chk = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint4 v = pre[j];                                  // (I0,Q0) (I1,Q1) (I2,Q2) (I3,Q3)
-            const int quad = j * 64 + lane;
-            auto lo16 = [](uint32_t w) { return (float)(short)(w & 0xffffu); };
-            auto hi16 = [](uint32_t w) { return (float)(short)(w >> 16); };
-            *reinterpret_cast<uint32_t*>(lds + oL(1, 0) + (HO + 2 * quad) * 2) = pk_h2(lo16(v.y), lo16(v.w));
-            *reinterpret_cast<uint32_t*>(lds + oL(1, 1) + (HO + 2 * quad) * 2) = pk_h2(hi16(v.y), hi16(v.w));
-            float* e0 = reinterpret_cast<float*>(lds + eA(1, 0)) + HE + 2 * quad;
-            float* e1 = reinterpret_cast<float*>(lds + eA(1, 1)) + HE + 2 * quad;
-            e0[0] = lo16(v.x); e0[1] = lo16(v.z);
-            e1[0] = hi16(v.x); e1[1] = hi16(v.z);
-            // 12-bit contract check on all 8 int16: (x + 0x0800) must have no bit above 11, per half
-            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-            const us2 bias = { 0x0800, 0x0800 };
-            auto ck = [&](uint32_t w) { chk |= __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, w) + bias)); };
-            ck(v.x); ck(v.y); ck(v.z); ck(v.w);
+            for (int j = 0; j < 4; j++) {
+                const uint4 v = pre[j];                                  // (I0,Q0) (I1,Q1) (I2,Q2) (I3,Q3)
+                const int quad = j * 64 + lane;
+                auto lo16 = [](uint32_t w) { return (float)(short)(w & 0xffffu); };
+                auto hi16 = [](uint32_t w) { return (float)(short)(w >> 16); };
+                *reinterpret_cast<uint32_t*>(lds + oL(1, 0) + (HO + 2 * quad) * 2) = pk_h2(lo16(v.y), lo16(v.w));
+                *reinterpret_cast<uint32_t*>(lds + oL(1, 1) + (HO + 2 * quad) * 2) = pk_h2(hi16(v.y), hi16(v.w));
+                float* e0 = reinterpret_cast<float*>(lds + eA(1, 0));
+                float* e1 = reinterpret_cast<float*>(lds + eA(1, 1));
+                const int p0 = e_phys(HE + 2 * quad), p1 = e_phys(HE + 2 * quad + 1);
+                e0[p0] = lo16(v.x); e0[p1] = lo16(v.z);
+                e1[p0] = hi16(v.x); e1[p1] = hi16(v.z);
+                // 12-bit contract check on all 8 int16: (x + 0x0800) must have no bit above 11, per half
+                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                const us2 bias = { 0x0800, 0x0800 };
+                auto ck = [&](uint32_t w) { chk |= __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, w) + bias)); };
+                ck(v.x); ck(v.y); ck(v.z); ck(v.w);
+            }
+            if (it + 1 < last) fetch(it + 1);
+            if (!bad && __any((chk & 0xf000f000u) != 0)) bad = true;
+            if (it >= first && lane == 0 && ((it + 1) % (CHUNK / S) == 0 || it + 1 == last))
+                flags[it / (CHUNK / S)] = bad ? 1u : 0u;
         }
-        if (sub + 1 < last) fetch(sub + 1);
-        if (!bad && __any((chk & 0xf000f000u) != 0)) bad = true;
-        __syncthreads();                                            // single-wave workgroup: a fence, no s_barrier
 
-        const bool live = sub >= first;
-        // ---- stages 1..6
-        static_for<1, L + 1>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            constexpr int NOUT = S >> s;                             // outputs per component and sub-chunk
-            constexpr bool MERGED = NOUT < 256;                      // I in columns [0, NC), Q in columns [8, 8 + NC): one tile for both
-            constexpr int NC = MERGED ? NOUT / 16 : 16;              // valid columns per component
-            constexpr int TILES = MERGED ? 1 : NOUT / 256;
-            constexpr int NCOMP = MERGED ? 1 : 2;
-            static_for<0, TILES * NCOMP>([&](auto tc) {
-                constexpr int t = decltype(tc)::value / NCOMP;
-                constexpr int cfix = decltype(tc)::value % NCOMP;
-                // component and column of this lane
-                const int comp = MERGED ? (n >> 3) : cfix;
-                const int col = MERGED ? (n & 7) : n;
-                const int colr = col < NC ? col : NC - 1;            // idle columns mirror a valid one (finite data, results dropped)
-                const bool valid = col < NC;
-                const int base = 256 * t + 16 * colr;                // arm index of window slot 0
-                const int cb = MERGED ? comp * comp_bytes(s) : 0;    // per-lane component select
-                const unsigned char* pl = lds + oL(s, MERGED ? 0 : cfix) + cb;
-                const h8 BaL = *reinterpret_cast<const h8*>(pl + (base + 8 * g) * 2);
-                const h8 BbL = *reinterpret_cast<const h8*>(pl + (base + 32 + 8 * (g & 1)) * 2);
-                f4 acc = { 0.f, 0.f, 0.f, 0.f };
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aa, BaL, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ab, BbL, acc, 0, 0, 0);
-                f4 acch = { 0.f, 0.f, 0.f, 0.f };
-                if constexpr (s >= 2) {
-                    const unsigned char* ph = pl + o_bytes(s);
-                    const h8 BaH = *reinterpret_cast<const h8*>(ph + (base + 8 * g) * 2);
-                    const h8 BbH = *reinterpret_cast<const h8*>(ph + (base + 32 + 8 * (g & 1)) * 2);
-                    acch = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aa, BaH, acch, 0, 0, 0);
-                    acch = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ab, BbH, acch, 0, 0, 0);
-                }
-                // centre tap: e[k - 15] for k = base + 4g + i  ->  even-arm entries (HE - 15) + base + 4g + i
-                const f4 ev = *reinterpret_cast<const f4*>(lds + eA(s, MERGED ? 0 : cfix) + cb + (base + 4 * g) * 4);
-                float y[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) y[i] = __builtin_floorf(acc[i] * 0x1p-11f) + acch[i] + ev[i];
-
-                if constexpr (s < L) {
-                    // lane (col, g) holds outputs k = 16 col + 4g + i: i = 1, 3 -> odd arm of stage s+1, i = 0, 2 -> even arm
-                    if (valid) {
-                        const int ko = 128 * t + 8 * col + 2 * g;                       // next-stage arm index of the pair
-                        constexpr int s2 = s + 1;
-                        const int cb2 = comp * comp_bytes(s2);
-                        const float h1 = __builtin_floorf(y[1] * 0x1p-11f), h3 = __builtin_floorf(y[3] * 0x1p-11f);
-                        const float l1 = __builtin_fmaf(h1, -2048.f, y[1]), l3 = __builtin_fmaf(h3, -2048.f, y[3]);
-                        unsigned char* po = lds + stage_off(s2) + cb2;
-                        *reinterpret_cast<uint32_t*>(po + (HO + ko) * 2) = pk_h2(l1, l3);
-                        *reinterpret_cast<uint32_t*>(po + o_bytes(s2) + (HO + ko) * 2) = pk_h2(h1, h3);
-                        float* pe = reinterpret_cast<float*>(po + o_bytes(s2) * 2) + HE + ko;
-                        pe[0] = y[0]; pe[1] = y[2];
+        // the stages, 6 down to 1; a group of stages = loads, then MFMAs, then epilogues
+        auto group = [&](auto lo_c, auto hi_c) {
+            constexpr int SLO = decltype(lo_c)::value, SHI = decltype(hi_c)::value;      // stages SHI down to SLO
+            // per stage: TILES * NCOMP tile-components; at most 4 (stage 1)
+            h8 BaL[SHI - SLO + 1][4], BbL[SHI - SLO + 1][4], BaH[SHI - SLO + 1][4], BbH[SHI - SLO + 1][4];
+            f4 ev[SHI - SLO + 1][4], acc[SHI - SLO + 1][4], acch[SHI - SLO + 1][4];
+            // -- loads
+            static_for<SLO, SHI + 1>([&](auto sc) {
+                constexpr int s = decltype(sc)::value, si = s - SLO;
+                constexpr int NOUT = S >> s;
+                constexpr bool MERGED = NOUT < 256;
+                constexpr int NC = MERGED ? NOUT / 16 : 16;
+                constexpr int NCOMP = MERGED ? 1 : 2, NTC = (MERGED ? 1 : NOUT / 256) * NCOMP;
+                static_for<0, NTC>([&](auto tcc) {
+                    constexpr int tc = decltype(tcc)::value, t = tc / NCOMP, cfix = tc % NCOMP;
+                    const int comp = MERGED ? (n >> 3) : cfix;
+                    const int col = MERGED ? (n & 7) : n;
+                    const int colr = col < NC ? col : NC - 1;                            // idle columns mirror a valid one (finite data, results dropped)
+                    const int base = 256 * t + 16 * colr;                                // arm index of window slot 0
+                    const int cb = MERGED ? comp * comp_bytes(s) : 0;
+                    const unsigned char* pl = lds + oL(s, MERGED ? 0 : cfix) + cb;
+                    BaL[si][tc] = *reinterpret_cast<const h8*>(pl + (base + 8 * g) * 2);
+                    BbL[si][tc] = *reinterpret_cast<const h8*>(pl + (base + 32 + 8 * (g & 1)) * 2);
+                    if constexpr (s >= 2) {
+                        BaH[si][tc] = *reinterpret_cast<const h8*>(pl + o_bytes(s) + (base + 8 * g) * 2);
+                        BbH[si][tc] = *reinterpret_cast<const h8*>(pl + o_bytes(s) + (base + 32 + 8 * (g & 1)) * 2);
                     }
-                } else {
-                    // final stage (merged tile: I in column 0, Q in column 8): meet in LDS, then pack Samples
-                    if (valid) {
-                        f4 yv = { y[0], y[1], y[2], y[3] };
-                        *reinterpret_cast<f4*>(lds + fin_off() + comp * 64 + g * 16) = yv;
-                    }
+                    // centre tap: e[k - 15] for k = base + 4g + i  ->  even-arm entries (HE - 15) + base + 4g + i
+                    ev[si][tc] = *reinterpret_cast<const f4*>(lds + eA(s, MERGED ? 0 : cfix) + cb + e_phys(base + 4 * g) * 4);
+                });
+            });
+            // -- matrix cores
+            static_for<SLO, SHI + 1>([&](auto sc) {
+                constexpr int s = decltype(sc)::value, si = s - SLO;
+                constexpr int NOUT = S >> s;
+                constexpr bool MERGED = NOUT < 256;
+                constexpr int NTC = (MERGED ? 1 : NOUT / 256) * (MERGED ? 1 : 2);
+                static_for<0, NTC>([&](auto tcc) {
+                    constexpr int tc = decltype(tcc)::value;
+                    const f4 z = { 0.f, 0.f, 0.f, 0.f };
+                    acc[si][tc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aa, BaL[si][tc], z, 0, 0, 0);
+                    acc[si][tc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ab, BbL[si][tc], acc[si][tc], 0, 0, 0);
+                    if constexpr (s >= 2) {
+                        acch[si][tc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aa, BaH[si][tc], z, 0, 0, 0);
+                        acch[si][tc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ab, BbH[si][tc], acch[si][tc], 0, 0, 0);
+                    } else acch[si][tc] = z;
+                });
+            });
+            // -- carry of the arrays these stages have just read (before the stages below overwrite their payload),
+            //    then epilogues: y, limb split, hand-over to the next stage's arrays
+            static_for<SLO, SHI + 1>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                constexpr int NL = n_limb(s);
+                // per component: NL x 16 dwords (odd-arm limb planes) + 15 dwords (even arm); lanes 0..(16 NL + 14)
+                const int plane = lane >> 4, w = lane & 15;
+                const bool isE = plane == NL;
+                const bool act = plane < NL || (isE && w < HE);
+                const int src = isE ? o_bytes(s) * NL + e_phys(n_arm(s) + w) * 4 : plane * o_bytes(s) + n_arm(s) * 2 + w * 4;
+                const int dst = isE ? o_bytes(s) * NL + w * 4 : plane * o_bytes(s) + w * 4;
+                if (act) {
+                    const uint32_t v0 = *reinterpret_cast<const uint32_t*>(lds + stage_off(s) + src);
+                    const uint32_t v1 = *reinterpret_cast<const uint32_t*>(lds + stage_off(s) + comp_bytes(s) + src);
+                    *reinterpret_cast<uint32_t*>(lds + stage_off(s) + dst) = v0;
+                    *reinterpret_cast<uint32_t*>(lds + stage_off(s) + comp_bytes(s) + dst) = v1;
                 }
             });
-            __syncthreads();
-        });
-        if (live && lane < (S >> L)) {
+            static_for<SLO, SHI + 1>([&](auto sc) {
+                constexpr int s = SHI + SLO - decltype(sc)::value, si = s - SLO;         // highest stage first
+                constexpr int NOUT = S >> s;
+                constexpr bool MERGED = NOUT < 256;
+                constexpr int NC = MERGED ? NOUT / 16 : 16;
+                constexpr int NCOMP = MERGED ? 1 : 2, NTC = (MERGED ? 1 : NOUT / 256) * NCOMP;
+                static_for<0, NTC>([&](auto tcc) {
+                    constexpr int tc = decltype(tcc)::value, t = tc / NCOMP, cfix = tc % NCOMP;
+                    const int comp = MERGED ? (n >> 3) : cfix;
+                    const int col = MERGED ? (n & 7) : n;
+                    const bool valid = col < NC;
+                    float y[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) y[i] = __builtin_floorf(acc[si][tc][i] * 0x1p-11f) + acch[si][tc][i] + ev[si][tc][i];
+                    if constexpr (s < L) {
+                        // lane (col, g) holds outputs k = 16 col + 4g + i: i = 1, 3 -> odd arm of stage s+1, i = 0, 2 -> even arm
+                        if (valid) {
+                            const int ko = 128 * t + 8 * col + 2 * g;                   // next-stage arm index of the pair
+                            constexpr int s2 = s + 1;
+                            const int cb2 = comp * comp_bytes(s2);
+                            const float h1 = __builtin_floorf(y[1] * 0x1p-11f), h3 = __builtin_floorf(y[3] * 0x1p-11f);
+                            const float l1 = __builtin_fmaf(h1, -2048.f, y[1]), l3 = __builtin_fmaf(h3, -2048.f, y[3]);
+                            unsigned char* po = lds + stage_off(s2) + cb2;
+                            *reinterpret_cast<uint32_t*>(po + (HO + ko) * 2) = pk_h2(l1, l3);
+                            *reinterpret_cast<uint32_t*>(po + o_bytes(s2) + (HO + ko) * 2) = pk_h2(h1, h3);
+                            float* pe = reinterpret_cast<float*>(po + o_bytes(s2) * 2);
+                            pe[e_phys(HE + ko)] = y[0]; pe[e_phys(HE + ko + 1)] = y[2];
+                        }
+                    } else {
+                        // final stage (merged tile: I in column 0, Q in column 8): meet in LDS, then pack Samples
+                        if (valid) {
+                            const f4 yv = { y[0], y[1], y[2], y[3] };
+                            *reinterpret_cast<f4*>(lds + fin_off() + comp * 64 + g * 16) = yv;
+                        }
+                    }
+                });
+            });
+        };
+        group(std::integral_constant<int, 3>{}, std::integral_constant<int, L>{});     // stages 6, 5, 4, 3: four merged tiles
+        group(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});     // stage 2 (two tiles) and stage 1 (four)
+
+        const long sub6 = it - (L - 1);                                                  // the sub-chunk stage 6 has just finished
+        if (sub6 >= first && sub6 < last && lane < (S >> L)) {
             const float yi = reinterpret_cast<const float*>(lds + fin_off())[lane];
             const float yq = reinterpret_cast<const float*>(lds + fin_off() + 64)[lane];
-            const long k = sub * (S >> L) + lane;
+            const long k = sub6 * (S >> L) + lane;
             if (k < n_out) {
                 const int re = (int)yi >> POST, im = (int)yq >> POST;
                 out[k] = ((uint32_t)re & 0xffffu) | ((uint32_t)im << 16);
             }
         }
-        if (live && lane == 0 && ((sub + 1) % (CHUNK / S) == 0 || sub + 1 == last))
-            flags[sub / (CHUNK / S)] = bad ? 1u : 0u;
-
-        // ---- carry: the last HO (HE) entries of every array become the next sub-chunk's history
-        static_for<1, L + 1>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            constexpr int NL = n_limb(s);
-            // per component: NL x 16 dwords (odd-arm limb planes) + 15 dwords (even arm); lanes 0..(16 NL + 14)
-            const int plane = lane >> 4, w = lane & 15;
-            const bool isE = plane == NL;
-            const bool act = plane < NL || (isE && w < HE);
-            const int src = isE ? o_bytes(s) * NL + (n_arm(s) + w) * 4 : plane * o_bytes(s) + n_arm(s) * 2 + w * 4;
-            const int dst = isE ? o_bytes(s) * NL + w * 4 : plane * o_bytes(s) + w * 4;
-            uint32_t v0 = 0, v1 = 0;
-            if (act) {
-                v0 = *reinterpret_cast<const uint32_t*>(lds + stage_off(s) + src);
-                v1 = *reinterpret_cast<const uint32_t*>(lds + stage_off(s) + comp_bytes(s) + src);
-            }
-            __syncthreads();
-            if (act) {
-                *reinterpret_cast<uint32_t*>(lds + stage_off(s) + dst) = v0;
-                *reinterpret_cast<uint32_t*>(lds + stage_off(s) + comp_bytes(s) + dst) = v1;
-            }
-        });
-        __syncthreads();
     }
 }
 

@@ -86,6 +86,23 @@ int sdrx_decim_process_dev(sdrx_decim_t* h, const int16_t* d_iq, int64_t n_int16
  * handles are served by consecutive launches of 64. */
 int sdrx_decim_process_dev_batch(sdrx_decim_t* const* handles, int32_t n_handles, const void* const* d_iq,
                                  const int64_t* n_elems, int16_t* const* d_out_iq, int64_t* n_out_cplx);
+/* Pinned, double-buffered HOST path (SURVEY 8b "Ownership": the async variant + sync).  The device thread's receive
+ * buffer IS a slot of a pinned ring the handle owns, so a block travels host -> HBM by DMA while the previous blocks are
+ * being decimated and their outputs travel back (limesdrinputthread.cpp:77-135: LMS_RecvStream(buf) -> decimate -> FIFO):
+ *     void* in = sdrx_decim_ring_acquire(h);            next free slot (NULL + last_error when the ring is full)
+ *     ... fill `in` with up to slot_elems elements ...
+ *     sdrx_decim_ring_submit(h, n_elems);               returns at once; same whole-group / tail-drop rule per block
+ *     sdrx_decim_ring_retire(h, &out, &n_out_cplx);     oldest submitted block: waits for it; `out` (pinned) stays valid
+ *                                                        until that slot is acquired again
+ * Blocks are retired in submission order.  `flush_slots` full blocks are coalesced into ONE copy + ONE launch (consecutive
+ * blocks of a stream are consecutive samples, and a full slot is a whole number of groups, so the result is identical to
+ * separate calls): 1 = every block at once (lowest latency), 16 = a LimeSDR-sized 32 768-sample block rate that is not
+ * bound by launch latency.  slot_elems: int16 per slot (bytes for the u8 flavour), a whole number of groups, bytes % 16 == 0. */
+int sdrx_decim_ring_create(sdrx_decim_t* h, int32_t slot_elems, int32_t n_slots, int32_t flush_slots);
+int sdrx_decim_ring_destroy(sdrx_decim_t* h);
+void* sdrx_decim_ring_acquire(sdrx_decim_t* h);
+int sdrx_decim_ring_submit(sdrx_decim_t* h, int32_t n_elems);
+int sdrx_decim_ring_retire(sdrx_decim_t* h, const int16_t** out_iq, int32_t* n_out_cplx);
 int sdrx_decim_sync(sdrx_decim_t* h);
 /* run on a caller-owned hipStream_t; NULL = the handle's own (non-blocking) stream.  The HIP default stream has the
  * handle value 0 and is therefore NOT selectable: work queued on it (PyTorch's default stream) is not ordered against the

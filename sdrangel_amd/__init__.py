@@ -67,6 +67,11 @@ def lib() -> C.CDLL:
         "sdrx_decim_process_dev": (C.c_int, [vp, vp, i64, vp, C.POINTER(i64)]),
         "sdrx_decim_process_dev_batch": (C.c_int, [vp, i32, vp, vp, vp, vp]),
         "sdrx_decim_sync": (C.c_int, [vp]),
+        "sdrx_decim_ring_create": (C.c_int, [vp, i32, i32, i32]),
+        "sdrx_decim_ring_destroy": (C.c_int, [vp]),
+        "sdrx_decim_ring_acquire": (vp, [vp]),
+        "sdrx_decim_ring_submit": (C.c_int, [vp, i32]),
+        "sdrx_decim_ring_retire": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i32)]),
         "sdrx_decim_set_stream": (C.c_int, [vp, vp]),
         "sdrx_decim_group_int16": (C.c_int, [C.c_int, C.c_int]),
         "sdrx_decim_state_bytes": (i64, [vp]),
@@ -205,6 +210,30 @@ class Decimators:
 
     def sync(self):
         _check(lib().sdrx_decim_sync(self._h), "sdrx_decim_sync")
+
+    # ---- pinned double-buffered host path: the receive buffer IS a slot of the handle's pinned ring
+    def ring_create(self, slot_elems: int, n_slots: int, flush_slots: int = 1):
+        _check(lib().sdrx_decim_ring_create(self._h, slot_elems, n_slots, flush_slots), "sdrx_decim_ring_create")
+        self._slot_elems = slot_elems
+
+    def ring_acquire(self) -> np.ndarray:
+        """numpy view of the next free pinned input slot (int16, or uint8 for DecimatorsU)"""
+        p = lib().sdrx_decim_ring_acquire(self._h)
+        if not p:
+            raise SdrxError(f"sdrx_decim_ring_acquire: {lib().sdrx_last_error().decode()}")
+        ct = C.c_uint8 if self.input_bits == 8 and isinstance(self, DecimatorsU) else C.c_int16
+        return np.ctypeslib.as_array((ct * self._slot_elems).from_address(p))
+
+    def ring_submit(self, n_elems: int):
+        _check(lib().sdrx_decim_ring_submit(self._h, n_elems), "sdrx_decim_ring_submit")
+
+    def ring_retire(self) -> np.ndarray:
+        """outputs of the oldest submitted block (a view of the pinned output slot: copy it before that slot is reused)"""
+        out, n = C.c_void_p(), C.c_int32()
+        _check(lib().sdrx_decim_ring_retire(self._h, C.byref(out), C.byref(n)), "sdrx_decim_ring_retire")
+        if n.value == 0:
+            return np.empty(0, np.int16)
+        return np.ctypeslib.as_array((C.c_int16 * (2 * n.value)).from_address(out.value))
 
     def set_stream(self, hip_stream: int | None):
         _check(lib().sdrx_decim_set_stream(self._h, hip_stream), "sdrx_decim_set_stream")

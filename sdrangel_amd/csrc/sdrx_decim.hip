@@ -4,6 +4,7 @@
 #include "decim_kernel.hpp"
 #include "decim_fast_kernel.hpp"
 #include <cstring>
+#include <vector>
 #include <utility>
 #include <cstdlib>
 #include <new>
@@ -116,6 +117,17 @@ struct sdrx_decim {
     char last_name[96] = "";
     int last_grid = 0, last_block = 0, last_lds = 0;
     EventTimer timer;
+    // pinned, double-buffered host path (sdrx_decim_ring_*): the caller's receive buffers ARE slots of this ring
+    struct Ring {
+        int n_slots = 0, flush = 1;
+        long slot_elems = 0, slot_out = 0;                          // input elements (int16 or bytes) and outputs per FULL slot
+        char* h_in = nullptr; char* h_out = nullptr;                // pinned
+        char* d_in = nullptr; char* d_out = nullptr;                // device mirrors, same slot layout
+        std::vector<hipEvent_t> ev;                                 // per slot; a run of slots flushed together completes on its last slot's event
+        std::vector<int> state, ev_of;                              // state: 0 free, 1 acquired, 2 submitted (not yet flushed), 3 in flight
+        std::vector<long> n_elems, n_out;
+        long head = 0, tail = 0, flushed = 0;                       // next to acquire / next to retire / next to flush (monotonic counters)
+    } ring;
 };
 
 static int group_int16(int log2, int fcpos)
@@ -247,6 +259,124 @@ static int launch(sdrx_decim* h, const void* d_iq, long n_cplx, int16_t* d_out)
     return launch_batch(&h, 1, &d_iq, &n_cplx, &d_out);
 }
 
+/* ---- pinned double-buffered host path ------------------------------------------------------------------------- */
+static void ring_free(sdrx_decim* h)
+{
+    sdrx_decim::Ring& r = h->ring;
+    for (hipEvent_t e : r.ev) if (e) (void)hipEventDestroy(e);
+    if (r.h_in) (void)hipHostFree(r.h_in);
+    if (r.h_out) (void)hipHostFree(r.h_out);
+    if (r.d_in) (void)hipFree(r.d_in);
+    if (r.d_out) (void)hipFree(r.d_out);
+    r = sdrx_decim::Ring();
+}
+
+static int ring_flush(sdrx_decim* h)
+{
+    sdrx_decim::Ring& r = h->ring;
+    const size_t esz = h->u8 ? 1 : 2;
+    while (r.flushed < r.head && r.state[(size_t)(r.flushed % r.n_slots)] == 2) {
+        // longest run of submitted FULL slots that is contiguous in the ring (no wrap): one copy in, one launch, one copy out.
+        // A short slot (fewer elements than the slot holds: its own tail-drop rule applies) travels alone.
+        const long s0 = r.flushed % r.n_slots;
+        const bool full0 = r.n_elems[(size_t)s0] == r.slot_elems;
+        long run = 1;
+        if (full0)
+            while (r.flushed + run < r.head && s0 + run < r.n_slots && r.state[(size_t)(s0 + run)] == 2 && r.n_elems[(size_t)(s0 + run)] == r.slot_elems) run++;
+        const long elems = full0 ? run * r.slot_elems : r.n_elems[(size_t)s0];
+        const long groups = elems / h->group;
+        const long n_cplx = groups * (h->group / 2), n_out = n_cplx >> h->log2;
+        const size_t in_off = (size_t)s0 * (size_t)r.slot_elems * esz, out_off = (size_t)s0 * (size_t)r.slot_out * 4;
+        if (elems) SDRX_HIP(hipMemcpyAsync(r.d_in + in_off, r.h_in + in_off, (size_t)elems * esz, hipMemcpyHostToDevice, h->stream));
+        int rc = launch(h, r.d_in + in_off, n_cplx, reinterpret_cast<int16_t*>(r.d_out + out_off)); if (rc) return rc;
+        if (n_out) SDRX_HIP(hipMemcpyAsync(r.h_out + out_off, r.d_out + out_off, (size_t)n_out * 4, hipMemcpyDeviceToHost, h->stream));
+        SDRX_HIP(hipEventRecord(r.ev[(size_t)(s0 + run - 1)], h->stream));
+        for (long k = 0; k < run; k++) {
+            const size_t sl = (size_t)(s0 + k);
+            r.state[sl] = 3; r.ev_of[sl] = (int)(s0 + run - 1);
+            r.n_out[sl] = full0 ? r.slot_out : n_out;
+        }
+        r.flushed += run;
+    }
+    return SDRX_OK;
+}
+
+extern "C" {
+
+int sdrx_decim_ring_create(sdrx_decim_t* h, int32_t slot_elems, int32_t n_slots, int32_t flush_slots)
+{
+    if (!h || n_slots < 2 || slot_elems <= 0) { set_error("sdrx_decim_ring_create: need a handle, >= 2 slots, a positive slot size"); return SDRX_EINVAL; }
+    if (slot_elems % h->group) { set_error("sdrx_decim_ring_create: the slot size must be a whole number of decimation groups (sdrx_decim_group_int16)"); return SDRX_EINVAL; }
+    if ((size_t)slot_elems * (h->u8 ? 1 : 2) % 16) { set_error("sdrx_decim_ring_create: slot bytes must be a multiple of 16"); return SDRX_EINVAL; }
+    SDRX_HIP(hipSetDevice(h->device));
+    SDRX_HIP(hipStreamSynchronize(h->stream));
+    ring_free(h);
+    sdrx_decim::Ring& r = h->ring;
+    r.n_slots = n_slots; r.flush = flush_slots < 1 ? 1 : (flush_slots > n_slots - 1 ? n_slots - 1 : flush_slots);
+    r.slot_elems = slot_elems; r.slot_out = (slot_elems / 2) >> h->log2;
+    const size_t in_bytes = (size_t)n_slots * (size_t)slot_elems * (h->u8 ? 1 : 2);
+    const size_t out_bytes = (size_t)n_slots * (size_t)(r.slot_out > 0 ? r.slot_out : 1) * 4;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&r.h_in), in_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r.h_out), out_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r.d_in), in_bytes + 64);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r.d_out), out_bytes + 64);
+    if (e != hipSuccess) { ring_free(h); return hip_fail(e, "sdrx_decim_ring_create", __FILE__, __LINE__); }
+    r.ev.assign((size_t)n_slots, nullptr); r.state.assign((size_t)n_slots, 0); r.ev_of.assign((size_t)n_slots, 0);
+    r.n_elems.assign((size_t)n_slots, 0); r.n_out.assign((size_t)n_slots, 0);
+    for (auto& ev : r.ev) { e = hipEventCreateWithFlags(&ev, hipEventDisableTiming); if (e != hipSuccess) { ring_free(h); return hip_fail(e, "hipEventCreate", __FILE__, __LINE__); } }
+    return SDRX_OK;
+}
+
+int sdrx_decim_ring_destroy(sdrx_decim_t* h)
+{
+    if (!h) return SDRX_EINVAL;
+    SDRX_HIP(hipSetDevice(h->device));
+    SDRX_HIP(hipStreamSynchronize(h->stream));
+    ring_free(h);
+    return SDRX_OK;
+}
+
+void* sdrx_decim_ring_acquire(sdrx_decim_t* h)
+{
+    if (!h || !h->ring.n_slots) { set_error("sdrx_decim_ring_acquire: no ring"); return nullptr; }
+    sdrx_decim::Ring& r = h->ring;
+    if (r.head - r.tail >= r.n_slots) { set_error("sdrx_decim_ring_acquire: ring full -- retire the oldest slot first"); return nullptr; }
+    const size_t sl = (size_t)(r.head % r.n_slots);
+    r.state[sl] = 1;                                                   // acquiring twice without a submit hands out the same slot
+    return r.h_in + sl * (size_t)r.slot_elems * (h->u8 ? 1 : 2);
+}
+
+int sdrx_decim_ring_submit(sdrx_decim_t* h, int32_t n_elems)
+{
+    if (!h || !h->ring.n_slots) { set_error("sdrx_decim_ring_submit: no ring"); return SDRX_ESTATE; }
+    sdrx_decim::Ring& r = h->ring;
+    const size_t sl = (size_t)(r.head % r.n_slots);
+    if (r.state[sl] != 1) { set_error("sdrx_decim_ring_submit: no acquired slot"); return SDRX_ESTATE; }
+    if (n_elems < 0 || n_elems > r.slot_elems) { set_error("sdrx_decim_ring_submit: more elements than the slot holds"); return SDRX_EINVAL; }
+    SDRX_HIP(hipSetDevice(h->device));
+    r.n_elems[sl] = n_elems; r.state[sl] = 2; r.head++;
+    // launch once `flush` slots are waiting, when the run reaches the end of the ring, or when the slot is short
+    if (r.head - r.flushed >= r.flush || r.head % r.n_slots == 0 || n_elems != r.slot_elems) return ring_flush(h);
+    return SDRX_OK;
+}
+
+int sdrx_decim_ring_retire(sdrx_decim_t* h, const int16_t** out_iq, int32_t* n_out_cplx)
+{
+    if (!h || !h->ring.n_slots || !out_iq || !n_out_cplx) { set_error("sdrx_decim_ring_retire: bad argument"); return SDRX_EINVAL; }
+    sdrx_decim::Ring& r = h->ring;
+    if (r.tail >= r.head) { set_error("sdrx_decim_ring_retire: nothing submitted"); return SDRX_ESTATE; }
+    SDRX_HIP(hipSetDevice(h->device));
+    const size_t sl = (size_t)(r.tail % r.n_slots);
+    if (r.state[sl] == 2) { int rc = ring_flush(h); if (rc) return rc; }
+    SDRX_HIP(hipEventSynchronize(r.ev[(size_t)r.ev_of[sl]]));
+    *out_iq = reinterpret_cast<const int16_t*>(r.h_out + sl * (size_t)r.slot_out * 4);
+    *n_out_cplx = (int32_t)r.n_out[sl];
+    r.state[sl] = 0; r.tail++;
+    return SDRX_OK;
+}
+
+} // extern "C"
+
 extern "C" {
 
 int sdrx_decim_group_int16(int log2_decim, int fcpos) { return group_int16(log2_decim, fcpos); }
@@ -305,6 +435,7 @@ int sdrx_decim_destroy(sdrx_decim_t* h)
     if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); }
     for (int i = 0; i < 2; i++) if (h->d_hist[i]) (void)hipFree(h->d_hist[i]);
     h->d_in.release(); h->d_out.release(); h->d_flags.release(); h->timer.release();
+    ring_free(h);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return SDRX_OK;
