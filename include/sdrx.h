@@ -331,6 +331,21 @@ int sdrx_dccorr_reset(sdrx_dccorr_t* h);
 int sdrx_dccorr_process(sdrx_dccorr_t* h, int16_t* iq, int64_t n_cplx);
 /* device buffers, asynchronous on the handle's stream; d_out_iq must not alias d_iq */
 int sdrx_dccorr_process_dev(sdrx_dccorr_t* h, const int16_t* d_iq, int16_t* d_out_iq, int64_t n_cplx);
+
+/* I/Q imbalance correction of the device stream: DSPDeviceSourceEngine::iqCorrections(begin, end, imbalanceCorrection = true)
+ * (dspdevicesourceengine.cpp:175-181, 217-253, float flavour: IMBALANCE_INT is not defined), i.e. DC removal + phase and
+ * amplitude imbalance estimated by 128-deep float/double moving averages, in the reference's statement order.  The
+ * recurrence is serial per stream, so ONE handle serves `n_streams` device streams side by side (one lane each).
+ * Buffers are rewritten in place like the reference rewrites the FIFO span.  State carries across calls; reset = freshly
+ * constructed engine members. */
+typedef struct sdrx_iqimb sdrx_iqimb_t;
+int sdrx_iqimb_create(sdrx_iqimb_t** h, int device, int32_t n_streams);
+int sdrx_iqimb_destroy(sdrx_iqimb_t* h);
+int sdrx_iqimb_reset(sdrx_iqimb_t* h);
+int sdrx_iqimb_process(sdrx_iqimb_t* h, int16_t* const* iq, const int64_t* n_cplx);
+int sdrx_iqimb_process_dev(sdrx_iqimb_t* h, const int16_t* const* d_iq, int16_t* const* d_out_iq, const int64_t* n_cplx);
+int sdrx_iqimb_sync(sdrx_iqimb_t* h);
+int sdrx_iqimb_set_stream(sdrx_iqimb_t* h, void* hip_stream);
 int sdrx_dccorr_sync(sdrx_dccorr_t* h);
 int sdrx_dccorr_set_stream(sdrx_dccorr_t* h, void* hip_stream);
 

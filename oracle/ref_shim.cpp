@@ -279,3 +279,47 @@ void ref_dccorr_process(void* h, const int16_t* iq, int64_t n_cplx, int16_t* out
     for (int64_t i = 0; i < n_cplx; i++) { out[2*i] = v[i].real(); out[2*i+1] = v[i].imag(); }
 }
 }
+
+
+// DC + I/Q imbalance correction as DSPDeviceSourceEngine::iqCorrections(begin, end, true) runs it with IMBALANCE_INT
+// undefined (dspdevicesourceengine.cpp:175-181, 217-253): the loop body on the reference's own MovingAverageUtil members
+// (dspdevicesourceengine.h:106-107, 120-125).  As for the DC-only case above, the engine class itself (a QThread wired to
+// the device and sink registries, iqCorrections private) is not instantiated; the loop's statements are.
+namespace { struct IqImb {
+    MovingAverageUtil<int32_t, int64_t, 1024> m_iBeta, m_qBeta;
+    MovingAverageUtil<float, double, 128> m_avgII, m_avgIQ, m_avgII2, m_avgQQ2;
+    MovingAverageUtil<double, double, 128> m_avgPhi, m_avgAmp;
+}; }
+extern "C" {
+void* ref_iqimb_new() { return new IqImb; }
+void ref_iqimb_free(void* h) { delete static_cast<IqImb*>(h); }
+void ref_iqimb_process(void* h, const int16_t* iq, int64_t n_cplx, int16_t* out)
+{
+    IqImb& d = *static_cast<IqImb*>(h);
+    SampleVector v((size_t) n_cplx);
+    for (int64_t i = 0; i < n_cplx; i++) v[i] = Sample(iq[2*i], iq[2*i+1]);
+    for (SampleVector::iterator it = v.begin(); it < v.end(); it++) {
+        d.m_iBeta(it->real());
+        d.m_qBeta(it->imag());
+        float xi = (it->m_real - (int32_t) d.m_iBeta) / SDR_RX_SCALEF;
+        float xq = (it->m_imag - (int32_t) d.m_qBeta) / SDR_RX_SCALEF;
+        d.m_avgII(xi*xi);
+        d.m_avgIQ(xi*xq);
+        if (d.m_avgII.asDouble() != 0) {
+            d.m_avgPhi(d.m_avgIQ.asDouble()/d.m_avgII.asDouble());
+        }
+        float& yi = xi;
+        float yq = xq - d.m_avgPhi.asDouble()*xi;
+        d.m_avgII2(yi*yi);
+        d.m_avgQQ2(yq*yq);
+        if (d.m_avgQQ2.asDouble() != 0) {
+            d.m_avgAmp(sqrt(d.m_avgII2.asDouble() / d.m_avgQQ2.asDouble()));
+        }
+        float& zi = yi;
+        float zq = d.m_avgAmp.asDouble() * yq;
+        it->m_real = zi * SDR_RX_SCALEF;
+        it->m_imag = zq * SDR_RX_SCALEF;
+    }
+    for (int64_t i = 0; i < n_cplx; i++) { out[2*i] = v[i].real(); out[2*i+1] = v[i].imag(); }
+}
+}

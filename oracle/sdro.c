@@ -14,6 +14,7 @@
 #include "sdro.h"
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 
 /* hbfiltertraits.cpp:136-154 / :85-99 -- (int32)(c * 4096), truncation toward zero */
 static const int32_t HB64[16] = { -1, 2, -5, 8, -12, 17, -25, 35, -47, 64, -86, 117, -164, 244, -424, 1300 };
@@ -310,5 +311,61 @@ void sdro_dccorr_process(sdro_dccorr* d, const int16_t* iq, int64_t n_cplx, int1
             nh[i] = src >= 0 ? iq[2 * src + comp] : d->hist[comp][i + n_cplx];
         }
         memcpy(d->hist[comp], nh, sizeof nh);
+    }
+}
+
+/* ------------------------------------------------------------------ DC + I/Q imbalance correction of the device stream
+ * DSPDeviceSourceEngine::iqCorrections(begin, end, true) with IMBALANCE_INT undefined (dspdevicesourceengine.cpp:175-181,
+ * 217-253; members dspdevicesourceengine.h:106-107,120-125).  Per sample, in this order:
+ *   m_iBeta(re); m_qBeta(im)                                        MovingAverageUtil<int32,int64,1024> (as sdro_dccorr)
+ *   xi = (re - (int32)m_iBeta) / 32768.f ; xq likewise              float
+ *   m_avgII(xi*xi); m_avgIQ(xi*xq)                                  MovingAverageUtil<float,double,128>
+ *   if (avgII != 0) m_avgPhi(avgIQ / avgII)                         MovingAverageUtil<double,double,128>, asDouble() = total / 128
+ *   yq = xq - avgPhi * xi                                           double arithmetic, rounded to float on assignment
+ *   m_avgII2(xi*xi); m_avgQQ2(yq*yq)
+ *   if (avgQQ2 != 0) m_avgAmp(sqrt(avgII2 / avgQQ2))
+ *   zq = avgAmp * yq                                                double, rounded to float
+ *   re' = (qint16)(xi * 32768.f) ; im' = (qint16)(zq * 32768.f)     float -> int (truncation) -> low 16 bits
+ * MovingAverageUtil<T,Total,N>::operator()(s) (util/movingaverage.h:42-56): while filling  total += s;  afterwards
+ * total += s - oldest  with the subtraction in T (float for the four power averages, double for phi / amp). */
+typedef struct { float s[128]; int n; unsigned idx; double total; } mavg_fd;
+typedef struct { double s[128]; int n; unsigned idx; double total; } mavg_dd;
+typedef struct { int32_t s[1024]; int n; unsigned idx; int64_t total; } mavg_i;
+
+static void mavg_fd_put(mavg_fd* m, float v)
+{
+    if (m->n < 128) { m->s[m->n++] = v; m->total += v; }
+    else { const float d = v - m->s[m->idx]; m->total += d; m->s[m->idx] = v; m->idx = (m->idx + 1) % 128; }
+}
+static void mavg_dd_put(mavg_dd* m, double v)
+{
+    if (m->n < 128) { m->s[m->n++] = v; m->total += v; }
+    else { const double d = v - m->s[m->idx]; m->total += d; m->s[m->idx] = v; m->idx = (m->idx + 1) % 128; }
+}
+static void mavg_i_put(mavg_i* m, int32_t v)
+{
+    if (m->n < 1024) { m->s[m->n++] = v; m->total += v; }
+    else { m->total += v - m->s[m->idx]; m->s[m->idx] = v; m->idx = (m->idx + 1) % 1024; }
+}
+
+struct sdro_iqimb { mavg_i iBeta, qBeta; mavg_fd II, IQ, II2, QQ2; mavg_dd Phi, Amp; };
+
+sdro_iqimb* sdro_iqimb_new(void) { return (sdro_iqimb*)calloc(1, sizeof(sdro_iqimb)); }
+void sdro_iqimb_free(sdro_iqimb* d) { free(d); }
+void sdro_iqimb_process(sdro_iqimb* d, const int16_t* iq, int64_t n_cplx, int16_t* out)
+{
+    for (int64_t n = 0; n < n_cplx; n++) {
+        const int re = iq[2 * n], im = iq[2 * n + 1];
+        mavg_i_put(&d->iBeta, re); mavg_i_put(&d->qBeta, im);
+        const float xi = (float)(re - (int32_t)(d->iBeta.total / 1024)) / 32768.0f;
+        const float xq = (float)(im - (int32_t)(d->qBeta.total / 1024)) / 32768.0f;
+        mavg_fd_put(&d->II, xi * xi); mavg_fd_put(&d->IQ, xi * xq);
+        if (d->II.total / 128 != 0) mavg_dd_put(&d->Phi, (d->IQ.total / 128) / (d->II.total / 128));
+        const float yq = (float)((double)xq - (d->Phi.total / 128) * (double)xi);
+        mavg_fd_put(&d->II2, xi * xi); mavg_fd_put(&d->QQ2, yq * yq);
+        if (d->QQ2.total / 128 != 0) mavg_dd_put(&d->Amp, sqrt((d->II2.total / 128) / (d->QQ2.total / 128)));
+        const float zq = (float)((d->Amp.total / 128) * (double)yq);
+        out[2 * n]     = (int16_t)(int32_t)(xi * 32768.0f);
+        out[2 * n + 1] = (int16_t)(int32_t)(zq * 32768.0f);
     }
 }

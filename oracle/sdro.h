@@ -91,6 +91,13 @@ sdro_dccorr* sdro_dccorr_new(void);
 void    sdro_dccorr_free(sdro_dccorr*);
 void    sdro_dccorr_process(sdro_dccorr*, const int16_t* iq, int64_t n_cplx, int16_t* out_iq);
 
+/* DSPDeviceSourceEngine::iqCorrections(begin, end, imbalanceCorrection = true), float flavour (IMBALANCE_INT undefined):
+ * dspdevicesourceengine.cpp:175-181, 217-253.  Strict IEEE, scalar (SURVEY finding 6). */
+typedef struct sdro_iqimb sdro_iqimb;
+sdro_iqimb* sdro_iqimb_new(void);
+void    sdro_iqimb_free(sdro_iqimb*);
+void    sdro_iqimb_process(sdro_iqimb*, const int16_t* iq, int64_t n_cplx, int16_t* out_iq);
+
 /* ---- float half-band decimators: DecimatorsFI / FF / IF over IntHalfbandFilterEOF<64> (oracle/sdro_fdecim.c) ----
  * in_kind 0: float I/Q, 1: int16 I/Q (DecimatorsIF<qint16,input_bits>); out_kind 0: int16 Sample (FI), 1: float (FF, IF).
  * n_elems = the reference's nbIAndQ; returns #complex outputs (whole groups only, tail dropped). */

@@ -114,6 +114,13 @@ def lib() -> C.CDLL:
         "sdrx_dccorr_process_dev": (C.c_int, [vp, vp, vp, C.c_int64]),
         "sdrx_dccorr_sync": (C.c_int, [vp]),
         "sdrx_dccorr_set_stream": (C.c_int, [vp, vp]),
+        "sdrx_iqimb_create": (C.c_int, [C.POINTER(vp), C.c_int, i32]),
+        "sdrx_iqimb_destroy": (C.c_int, [vp]),
+        "sdrx_iqimb_reset": (C.c_int, [vp]),
+        "sdrx_iqimb_process": (C.c_int, [vp, vp, vp]),
+        "sdrx_iqimb_process_dev": (C.c_int, [vp, vp, vp, vp]),
+        "sdrx_iqimb_sync": (C.c_int, [vp]),
+        "sdrx_iqimb_set_stream": (C.c_int, [vp, vp]),
         "sdrx_fdecim_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
         "sdrx_fdecim_destroy": (C.c_int, [vp]),
         "sdrx_fdecim_reset": (C.c_int, [vp]),
@@ -601,6 +608,33 @@ class BackendBank:
         _check(lib().sdrx_backend_get_design(self._h, ch, C.byref(nt), taps.ctypes.data, taps.size, filt.ctypes.data, C.byref(inc)),
                "sdrx_backend_get_design")
         return nt.value, taps[: 16 * nt.value].copy(), filt, inc.value
+
+
+class IqImbalance:
+    """DSPDeviceSourceEngine::iqCorrections(begin, end, true) (DC + I/Q imbalance, float flavour) for N device streams."""
+
+    def __init__(self, n_streams: int, device: int = 0):
+        self.n = n_streams
+        self._h = C.c_void_p()
+        _check(lib().sdrx_iqimb_create(C.byref(self._h), device, n_streams), "sdrx_iqimb_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sdrx_iqimb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def reset(self):
+        _check(lib().sdrx_iqimb_reset(self._h), "sdrx_iqimb_reset")
+
+    def process(self, per_stream_iq):
+        """in place on copies: returns the corrected int16 I/Q per stream"""
+        bufs = [_i16(x).copy() for x in per_stream_iq]
+        ptrs = (C.c_void_p * self.n)(*[b.ctypes.data for b in bufs])
+        ns = (C.c_int64 * self.n)(*[b.size // 2 for b in bufs])
+        _check(lib().sdrx_iqimb_process(self._h, ptrs, ns), "sdrx_iqimb_process")
+        return bufs
 
 
 class SampleSinkFifo:

@@ -123,6 +123,8 @@ struct sdrx_decim {
         long slot_elems = 0, slot_out = 0;                          // input elements (int16 or bytes) and outputs per FULL slot
         char* h_in = nullptr; char* h_out = nullptr;                // pinned
         char* d_in = nullptr; char* d_out = nullptr;                // device mirrors, same slot layout
+        hipStream_t s_in = nullptr, s_out = nullptr;                // copy streams: H2D of run k+1 overlaps kernel k and D2H k-1
+        std::vector<hipEvent_t> ev_in, ev_k;                        // per slot: its run's H2D done / kernels done
         std::vector<hipEvent_t> ev;                                 // per slot; a run of slots flushed together completes on its last slot's event
         std::vector<int> state, ev_of;                              // state: 0 free, 1 acquired, 2 submitted (not yet flushed), 3 in flight
         std::vector<long> n_elems, n_out;
@@ -264,6 +266,10 @@ static void ring_free(sdrx_decim* h)
 {
     sdrx_decim::Ring& r = h->ring;
     for (hipEvent_t e : r.ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : r.ev_in) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : r.ev_k) if (e) (void)hipEventDestroy(e);
+    if (r.s_in) { (void)hipStreamSynchronize(r.s_in); (void)hipStreamDestroy(r.s_in); }
+    if (r.s_out) { (void)hipStreamSynchronize(r.s_out); (void)hipStreamDestroy(r.s_out); }
     if (r.h_in) (void)hipHostFree(r.h_in);
     if (r.h_out) (void)hipHostFree(r.h_out);
     if (r.d_in) (void)hipFree(r.d_in);
@@ -287,10 +293,16 @@ static int ring_flush(sdrx_decim* h)
         const long groups = elems / h->group;
         const long n_cplx = groups * (h->group / 2), n_out = n_cplx >> h->log2;
         const size_t in_off = (size_t)s0 * (size_t)r.slot_elems * esz, out_off = (size_t)s0 * (size_t)r.slot_out * 4;
-        if (elems) SDRX_HIP(hipMemcpyAsync(r.d_in + in_off, r.h_in + in_off, (size_t)elems * esz, hipMemcpyHostToDevice, h->stream));
+        // three streams, chained by events: copy in -> kernels (the handle's stream, where the filter state lives) -> copy out
+        const size_t last = (size_t)(s0 + run - 1);
+        if (elems) SDRX_HIP(hipMemcpyAsync(r.d_in + in_off, r.h_in + in_off, (size_t)elems * esz, hipMemcpyHostToDevice, r.s_in));
+        SDRX_HIP(hipEventRecord(r.ev_in[last], r.s_in));
+        SDRX_HIP(hipStreamWaitEvent(h->stream, r.ev_in[last], 0));
         int rc = launch(h, r.d_in + in_off, n_cplx, reinterpret_cast<int16_t*>(r.d_out + out_off)); if (rc) return rc;
-        if (n_out) SDRX_HIP(hipMemcpyAsync(r.h_out + out_off, r.d_out + out_off, (size_t)n_out * 4, hipMemcpyDeviceToHost, h->stream));
-        SDRX_HIP(hipEventRecord(r.ev[(size_t)(s0 + run - 1)], h->stream));
+        SDRX_HIP(hipEventRecord(r.ev_k[last], h->stream));
+        SDRX_HIP(hipStreamWaitEvent(r.s_out, r.ev_k[last], 0));
+        if (n_out) SDRX_HIP(hipMemcpyAsync(r.h_out + out_off, r.d_out + out_off, (size_t)n_out * 4, hipMemcpyDeviceToHost, r.s_out));
+        SDRX_HIP(hipEventRecord(r.ev[last], r.s_out));
         for (long k = 0; k < run; k++) {
             const size_t sl = (size_t)(s0 + k);
             r.state[sl] = 3; r.ev_of[sl] = (int)(s0 + run - 1);
@@ -321,9 +333,14 @@ int sdrx_decim_ring_create(sdrx_decim_t* h, int32_t slot_elems, int32_t n_slots,
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r.d_in), in_bytes + 64);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r.d_out), out_bytes + 64);
     if (e != hipSuccess) { ring_free(h); return hip_fail(e, "sdrx_decim_ring_create", __FILE__, __LINE__); }
-    r.ev.assign((size_t)n_slots, nullptr); r.state.assign((size_t)n_slots, 0); r.ev_of.assign((size_t)n_slots, 0);
+    r.ev.assign((size_t)n_slots, nullptr); r.ev_in.assign((size_t)n_slots, nullptr); r.ev_k.assign((size_t)n_slots, nullptr);
+    r.state.assign((size_t)n_slots, 0); r.ev_of.assign((size_t)n_slots, 0);
     r.n_elems.assign((size_t)n_slots, 0); r.n_out.assign((size_t)n_slots, 0);
-    for (auto& ev : r.ev) { e = hipEventCreateWithFlags(&ev, hipEventDisableTiming); if (e != hipSuccess) { ring_free(h); return hip_fail(e, "hipEventCreate", __FILE__, __LINE__); } }
+    for (auto* v : { &r.ev, &r.ev_in, &r.ev_k })
+        for (auto& ev : *v) { e = hipEventCreateWithFlags(&ev, hipEventDisableTiming); if (e != hipSuccess) { ring_free(h); return hip_fail(e, "hipEventCreate", __FILE__, __LINE__); } }
+    e = hipStreamCreateWithFlags(&r.s_in, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r.s_out, hipStreamNonBlocking);
+    if (e != hipSuccess) { ring_free(h); return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
     return SDRX_OK;
 }
 

@@ -239,3 +239,24 @@ class DcCorr:
         out = np.empty_like(iq)
         self.L.sdro_dccorr_process(self.h, iq.ctypes.data, iq.size // 2, out.ctypes.data)
         return out
+
+
+class IqImb:
+    """oracle of DSPDeviceSourceEngine::iqCorrections(.., imbalanceCorrection=true), float flavour (oracle/sdro.c)"""
+
+    def __init__(self):
+        self.L = lib()
+        self.L.sdro_iqimb_new.restype = C.c_void_p
+        self.L.sdro_iqimb_free.argtypes = [C.c_void_p]
+        self.L.sdro_iqimb_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        self.h = self.L.sdro_iqimb_new()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.sdro_iqimb_free(self.h); self.h = None
+
+    def process(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.int16)
+        out = np.empty_like(iq)
+        self.L.sdro_iqimb_process(self.h, iq.ctypes.data, iq.size // 2, out.ctypes.data)
+        return out

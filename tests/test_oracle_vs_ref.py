@@ -196,6 +196,28 @@ def test_dc_offset_correction_vs_moving_average_util():
     R.ref_dccorr_free(h)
 
 
+def test_iq_imbalance_correction_vs_reference_members():
+    """oracle I/Q imbalance correction vs the loop of iqCorrections(.., true) on the reference's own MovingAverageUtil members
+    (float/double averages, division and sqrt per sample), strict-IEEE build; ragged calls, DC + amplitude + phase imbalance"""
+    R = C.CDLL(REF)
+    R.ref_iqimb_new.restype = C.c_void_p
+    R.ref_iqimb_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    R.ref_iqimb_free.argtypes = [C.c_void_p]
+    h = R.ref_iqimb_new(); o = orc.IqImb()
+    rng = np.random.default_rng(8)
+    for n in (3, 127, 128, 129, 1, 1024, 0, 50000, 777):
+        i = rng.integers(-12000, 12000, n); q = (0.8 * rng.integers(-12000, 12000, n) + 0.1 * i + 300).astype(np.int64)
+        x = np.empty(2 * n, np.int16); x[0::2] = (i + 200).clip(-32768, 32767); x[1::2] = q.clip(-32768, 32767)
+        want = np.zeros(2 * n + 2, np.int16)
+        R.ref_iqimb_process(h, x.ctypes.data, n, want.ctypes.data)
+        assert np.array_equal(o.process(x), want[: 2 * n]), n
+    z = np.zeros(2 * 500, np.int16)                          # all-zero input: both `!= 0` guards take the skip branch
+    want = np.zeros(2 * 500, np.int16)
+    R.ref_iqimb_process(h, z.ctypes.data, 500, want.ctypes.data)
+    assert np.array_equal(o.process(z), want)
+    R.ref_iqimb_free(h)
+
+
 def test_sample_sink_fifo_mirror_vs_the_real_class():
     """sdrx_fifo_* against the reference's SampleSinkFifo (QObject, built with moc into oracle/_ref/libsdrref_qt.so): 2400
     random write / write(bytes) / read / readBegin / readCommit operations incl. overflow and underflow; the same child also
