@@ -28,3 +28,22 @@ def test_reference_objects_and_gpu_adapter_agree_in_one_process():
     assert out.stdout.count(" OK ") >= 12 * 2 + 12 + 6, out.stdout
     assert out.stdout.count("engine chain: decimate8_cen -> FIFO -> work() + DC corr -> channel") == 6
     assert "MISMATCH" not in out.stdout
+
+
+ENG = os.path.join(ROOT, "oracle", "_ref", "dropin_engine_test")
+
+
+@pytest.mark.skipif(not (os.path.exists(ENG) and os.path.exists(QT)), reason="engine drop-in harness not built (needs /root/reference + Qt at build time)")
+def test_real_engine_and_gpu_engine_agree_in_one_process():
+    """oracle/dropin_engine_test.cpp: the REAL DSPDeviceSourceEngine (QThread + SyncMessenger, compiled from the reference's
+    own dspdevicesourceengine.cpp) next to qt_adapter/GpuDeviceSourceEngine: same source FIFO traffic, same sinks; the sample
+    streams the sinks receive (no correction / DC / DC + I/Q imbalance, reconfigured mid-stream), the channel outputs
+    (3 real DownChannelizers vs one GpuDownChannelizerBank) and the state machine must agree."""
+    env = dict(os.environ)
+    sys_stdcpp = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
+    if os.path.exists(sys_stdcpp):
+        env["LD_PRELOAD"] = sys_stdcpp
+    out = subprocess.run([ENG], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, (out.returncode, out.stdout[-3000:], out.stderr[-2000:])
+    assert "ENGINE DROP-IN: ALL OK" in out.stdout
+    assert out.stdout.count("identical") == 3 + 3 and "DIFFERENT" not in out.stdout and "FAIL" not in out.stdout
