@@ -227,6 +227,42 @@ int sdrx_backend_get_design(sdrx_backend_t* h, int32_t ch, int32_t* ntaps_per_ph
 int sdrx_backend_sync(sdrx_backend_t* h);
 
 /* ------------------------------------------------------------------------------------------
+ * Audio-rate tail of the NFM and SSB demodulators -- what follows the resampler / fftfilt in
+ * NFMDemod::feed (plugins/channelrx/demodnfm/nfmdemod.cpp:150-300; m_deltaSquelch, m_ctcssOn, m_audioMute off) and
+ * SSBDemod::feed (plugins/channelrx/demodssb/ssbdemod.cpp:181-250; mono): discriminator + power squelch + gate delay
+ * line + 301-tap Bandpass for NFM, MagAGC (sdrbase/dsp/agc.cpp:96-175) + delay line + step value for SSB, down to the
+ * qint16 the demod writes to both channels of m_audioBuffer.  Input per channel: the complex float stream the demod body
+ * sees (sdrx_backend_* with discri = 0: resampler output for NFM, fftfilt sideband for SSB).  One output per input.
+ * Serial state machines: one lane per channel, N channels per handle.  m_prevArg of the reference's PhaseDiscriminators
+ * is uninitialised (phasediscri.h:139); it starts at 0 here.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sdrx_audiotail sdrx_audiotail_t;
+typedef struct sdrx_audiotail_cfg {
+    int32_t kind;                 /* 0 NFM, 1 SSB */
+    int32_t audio_rate;           /* m_audioSampleRate (48000) */
+    float   volume;               /* m_settings.m_volume (NFM) / m_volume (SSB) */
+    /* NFM */
+    float   fm_scaling;           /* m_phaseDiscri.setFMScaling(): (float) audioRate / (2 * fmDeviation) */
+    float   squelch_level;        /* m_squelchLevel: linear power */
+    int32_t squelch_gate;         /* m_squelchGate, samples */
+    float   af_bandwidth;         /* m_bandpass.create(301, rate, 300.0, af_bandwidth) */
+    /* SSB: MagAGC(12000, agcTarget, 1e-2) after resize(n, n / 2, agcTarget), setStepDownDelay(n) (ssbdemod.cpp:411-414) */
+    int32_t agc_active;           /* settings.m_agc; off: agcVal = 10.0 */
+    int32_t agc_nb_samples;       /* (audioRate / 1000) * (1 << agcTimeLog2) */
+    int32_t agc_threshold_enable; /* setThresholdEnable */
+    int32_t agc_gate;             /* setGate, samples */
+    int32_t agc_clamping;         /* setClamping; clampMax = SDR_RX_SCALED / 100 */
+    double  agc_threshold;        /* setThreshold: powerFromdB(dB) * 32768^2 */
+} sdrx_audiotail_cfg;
+int sdrx_audiotail_create(sdrx_audiotail_t** h, int device, int32_t n_ch, const sdrx_audiotail_cfg* cfg);
+int sdrx_audiotail_destroy(sdrx_audiotail_t* h);
+int sdrx_audiotail_reset(sdrx_audiotail_t* h);
+/* in[c]: n[c] complex floats (re, im); audio[c]: n[c] qint16 (the value written to .l and .r) */
+int sdrx_audiotail_feed(sdrx_audiotail_t* h, const float* const* in, const int64_t* n, int16_t* const* audio);
+int sdrx_audiotail_feed_dev(sdrx_audiotail_t* h, const float* const* d_in, const int64_t* n, int16_t* const* d_audio);
+int sdrx_audiotail_sync(sdrx_audiotail_t* h);
+
+/* ------------------------------------------------------------------------------------------
  * Lowpass<Real> / Bandpass<Real> (sdrbase/dsp/lowpass.h:11-105, bandpass.h:11-128): the symmetric-folded real
  * FIRs of the demods' audio tail (NFM: m_lowpass.create(301, rate, 250.0), m_bandpass.create(301, rate, 300.0, bw),
  * nfmdemod.cpp:88,428-429; filter() per audio sample :239,279), N channels per handle, state carried across feeds.

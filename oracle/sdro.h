@@ -101,6 +101,17 @@ void    sdro_iqimb_process(sdro_iqimb*, const int16_t* iq, int64_t n_cplx, int16
 /* ---- float half-band decimators: DecimatorsFI / FF / IF over IntHalfbandFilterEOF<64> (oracle/sdro_fdecim.c) ----
  * in_kind 0: float I/Q, 1: int16 I/Q (DecimatorsIF<qint16,input_bits>); out_kind 0: int16 Sample (FI), 1: float (FF, IF).
  * n_elems = the reference's nbIAndQ; returns #complex outputs (whole groups only, tail dropped). */
+/* audio-rate tails of the NFM / SSB demodulators (oracle/sdro_audio.c) */
+typedef struct sdro_nfmtail sdro_nfmtail;
+sdro_nfmtail* sdro_nfmtail_new(int32_t audio_rate, float fm_scaling, float squelch_level, int32_t squelch_gate, float volume, float af_bandwidth);
+void    sdro_nfmtail_free(sdro_nfmtail*);
+void    sdro_nfmtail_process(sdro_nfmtail*, const float* ci, int64_t n, int16_t* audio);
+typedef struct sdro_ssbtail sdro_ssbtail;
+sdro_ssbtail* sdro_ssbtail_new(int32_t agc_active, int32_t agc_nb_samples, double agc_threshold, int32_t agc_threshold_enable,
+                               int32_t agc_gate, int32_t agc_clamping, float volume);
+void    sdro_ssbtail_free(sdro_ssbtail*);
+void    sdro_ssbtail_process(sdro_ssbtail*, const float* sideband, int64_t n, int16_t* audio);
+
 typedef struct sdro_fdecim sdro_fdecim;
 sdro_fdecim* sdro_fdecim_new(int log2_decim, int fcpos, int in_kind, int out_kind, int input_bits);
 void    sdro_fdecim_free(sdro_fdecim*);

@@ -135,6 +135,12 @@ def lib() -> C.CDLL:
         "sdrx_backend_read": (i64, [vp, i32, vp, i64]),
         "sdrx_backend_get_design": (C.c_int, [vp, i32, C.POINTER(i32), vp, i32, vp, C.POINTER(i32)]),
         "sdrx_backend_sync": (C.c_int, [vp]),
+        "sdrx_audiotail_create": (C.c_int, [pp, C.c_int, i32, vp]),
+        "sdrx_audiotail_destroy": (C.c_int, [vp]),
+        "sdrx_audiotail_reset": (C.c_int, [vp]),
+        "sdrx_audiotail_feed": (C.c_int, [vp, vp, vp, vp]),
+        "sdrx_audiotail_feed_dev": (C.c_int, [vp, vp, vp, vp]),
+        "sdrx_audiotail_sync": (C.c_int, [vp]),
         "sdrx_firbank_create": (C.c_int, [pp, C.c_int, i32, vp]),
         "sdrx_firbank_destroy": (C.c_int, [vp]),
         "sdrx_firbank_feed": (C.c_int, [vp, vp, vp, vp]),
@@ -608,6 +614,43 @@ class BackendBank:
         _check(lib().sdrx_backend_get_design(self._h, ch, C.byref(nt), taps.ctypes.data, taps.size, filt.ctypes.data, C.byref(inc)),
                "sdrx_backend_get_design")
         return nt.value, taps[: 16 * nt.value].copy(), filt, inc.value
+
+
+class AudioTailCfg(C.Structure):
+    """sdrx_audiotail_cfg (include/sdrx.h)"""
+    _fields_ = [("kind", C.c_int32), ("audio_rate", C.c_int32), ("volume", C.c_float),
+                ("fm_scaling", C.c_float), ("squelch_level", C.c_float), ("squelch_gate", C.c_int32), ("af_bandwidth", C.c_float),
+                ("agc_active", C.c_int32), ("agc_nb_samples", C.c_int32), ("agc_threshold_enable", C.c_int32), ("agc_gate", C.c_int32),
+                ("agc_clamping", C.c_int32), ("agc_threshold", C.c_double)]
+
+
+class AudioTail:
+    """audio-rate tail of the NFM / SSB demods (squelch / MagAGC / delay line / Bandpass -> qint16) for N channels"""
+
+    def __init__(self, cfgs, device: int = 0):
+        self.n_ch = len(cfgs)
+        arr = (AudioTailCfg * self.n_ch)(*cfgs)
+        self._h = C.c_void_p()
+        _check(lib().sdrx_audiotail_create(C.byref(self._h), device, self.n_ch, arr), "sdrx_audiotail_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sdrx_audiotail_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def reset(self):
+        _check(lib().sdrx_audiotail_reset(self._h), "sdrx_audiotail_reset")
+
+    def feed(self, per_channel_cplx):
+        ins = [np.ascontiguousarray(x, dtype=np.float32) for x in per_channel_cplx]
+        outs = [np.zeros(max(x.size // 2, 1), np.int16) for x in ins]
+        pi = (C.c_void_p * self.n_ch)(*[x.ctypes.data for x in ins])
+        po = (C.c_void_p * self.n_ch)(*[x.ctypes.data for x in outs])
+        ns = (C.c_int64 * self.n_ch)(*[x.size // 2 for x in ins])
+        _check(lib().sdrx_audiotail_feed(self._h, pi, ns, po), "sdrx_audiotail_feed")
+        return [o[: x.size // 2] for o, x in zip(outs, ins)]
 
 
 class IqImbalance:

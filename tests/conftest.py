@@ -18,7 +18,7 @@ def _built():
     """Build the checker (oracle) once per session; the product .so is built by __graft_entry__.build()."""
     import subprocess
     so = os.path.join(ROOT, "oracle", "libsdro.so")
-    src = [os.path.join(ROOT, "oracle", f) for f in ("sdro.c", "sdro_float.c", "sdro.h")]
+    src = [os.path.join(ROOT, "oracle", f) for f in ("sdro.c", "sdro_float.c", "sdro_fdecim.c", "sdro_audio.c", "sdro.h")]
     src = [s for s in src if os.path.exists(s)]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libsdro.so"])

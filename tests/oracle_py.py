@@ -260,3 +260,29 @@ class IqImb:
         out = np.empty_like(iq)
         self.L.sdro_iqimb_process(self.h, iq.ctypes.data, iq.size // 2, out.ctypes.data)
         return out
+
+
+class AudioTailOracle:
+    """oracle/sdro_audio.c: kind 0 = NFM tail, 1 = SSB tail"""
+
+    def __init__(self, kind, **k):
+        self.L = lib(); self.kind = kind
+        L = self.L
+        L.sdro_nfmtail_new.restype = C.c_void_p; L.sdro_nfmtail_new.argtypes = [C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_float]
+        L.sdro_nfmtail_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]; L.sdro_nfmtail_free.argtypes = [C.c_void_p]
+        L.sdro_ssbtail_new.restype = C.c_void_p; L.sdro_ssbtail_new.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_float]
+        L.sdro_ssbtail_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]; L.sdro_ssbtail_free.argtypes = [C.c_void_p]
+        if kind == 0:
+            self.h = L.sdro_nfmtail_new(k["audio_rate"], k["fm_scaling"], k["squelch_level"], k["squelch_gate"], k["volume"], k["af_bandwidth"])
+        else:
+            self.h = L.sdro_ssbtail_new(k["agc_active"], k["agc_nb_samples"], k["agc_threshold"], k["agc_threshold_enable"], k["agc_gate"], k["agc_clamping"], k["volume"])
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            (self.L.sdro_nfmtail_free if self.kind == 0 else self.L.sdro_ssbtail_free)(self.h); self.h = None
+
+    def feed(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.zeros(max(x.size // 2, 1), np.int16)
+        (self.L.sdro_nfmtail_process if self.kind == 0 else self.L.sdro_ssbtail_process)(self.h, x.ctypes.data, x.size // 2, out.ctypes.data)
+        return out[: x.size // 2]

@@ -218,6 +218,29 @@ def test_iq_imbalance_correction_vs_reference_members():
     R.ref_iqimb_free(h)
 
 
+def test_nfm_and_ssb_audio_tails_vs_reference_members():
+    """oracle/sdro_audio.c vs the NFM / SSB demod loop bodies on the reference's own PhaseDiscriminators, MovingAverageUtil,
+    DoubleBufferFIFO, Bandpass<Real> and MagAGC (agc.cpp compiled where it lies): qint16 audio identical, ragged calls"""
+    from tests.test_audiotail_gpu import NFM, SSB, bursts
+    R = C.CDLL(REF)
+    R.ref_nfmtail_new.restype = C.c_void_p; R.ref_nfmtail_new.argtypes = [C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_float]
+    R.ref_nfmtail_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    R.ref_ssbtail_new.restype = C.c_void_p; R.ref_ssbtail_new.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_float]
+    R.ref_ssbtail_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    n = 110_000
+    for i, k in enumerate(NFM + SSB):
+        x = bursts(n, 300 + i, period=15000 if i % 2 else 9000)
+        o = orc.AudioTailOracle(**k)
+        if k["kind"] == 0:
+            h = R.ref_nfmtail_new(k["audio_rate"], k["fm_scaling"], k["squelch_level"], k["squelch_gate"], k["volume"], k["af_bandwidth"]); run = R.ref_nfmtail_process
+        else:
+            h = R.ref_ssbtail_new(k["agc_active"], k["agc_nb_samples"], k["agc_threshold"], k["agc_threshold_enable"], k["agc_gate"], k["agc_clamping"], k["volume"]); run = R.ref_ssbtail_process
+        for a, b in ((0, 5), (5, 40_000), (40_000, n)):
+            seg = np.ascontiguousarray(x[2 * a: 2 * b]); want = np.zeros(b - a, np.int16)
+            run(h, seg.ctypes.data, b - a, want.ctypes.data)
+            assert np.array_equal(o.feed(seg), want), (i, a, b)
+
+
 def test_sample_sink_fifo_mirror_vs_the_real_class():
     """sdrx_fifo_* against the reference's SampleSinkFifo (QObject, built with moc into oracle/_ref/libsdrref_qt.so): 2400
     random write / write(bytes) / read / readBegin / readCommit operations incl. overflow and underflow; the same child also
