@@ -263,6 +263,19 @@ int sdrx_audiotail_feed_dev(sdrx_audiotail_t* h, const float* const* d_in, const
 int sdrx_audiotail_sync(sdrx_audiotail_t* h);
 
 /* ------------------------------------------------------------------------------------------
+ * IIRFilter<float, Order> (sdrbase/dsp/iirfilter.h; FilterMbe's low/high-pass pair, filtermbe.h:76-77): N recursive
+ * filters, one per channel, state carried across feeds.  `a` / `b` are the constructor's arguments in the reference's
+ * meaning: order 2 = the specialisation (y = b0 s + b1 x0 + b2 x1 + a1 y0 + a2 y1); other orders = the generic template,
+ * including its swapped coefficient copy (iirfilter.h:78-81).  Serial along time: one lane per channel.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sdrx_iir sdrx_iir_t;
+typedef struct sdrx_iir_cfg { int32_t order; float a[9]; float b[9]; } sdrx_iir_cfg;   /* order 2..8, order + 1 coefficients each */
+int sdrx_iir_create(sdrx_iir_t** h, int device, int32_t n_ch, const sdrx_iir_cfg* cfg);
+int sdrx_iir_destroy(sdrx_iir_t* h);
+int sdrx_iir_reset(sdrx_iir_t* h);
+int sdrx_iir_feed(sdrx_iir_t* h, const float* const* in, const int64_t* n, float* const* out);
+
+/* ------------------------------------------------------------------------------------------
  * Lowpass<Real> / Bandpass<Real> (sdrbase/dsp/lowpass.h:11-105, bandpass.h:11-128): the symmetric-folded real
  * FIRs of the demods' audio tail (NFM: m_lowpass.create(301, rate, 250.0), m_bandpass.create(301, rate, 300.0, bw),
  * nfmdemod.cpp:88,428-429; filter() per audio sample :239,279), N channels per handle, state carried across feeds.

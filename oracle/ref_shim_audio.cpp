@@ -111,3 +111,28 @@ void ref_ssbtail_process(void* h, const float* sb, int64_t n, int16_t* audio)
 }
 
 }
+
+
+// IIRFilter<float, Order> (sdrbase/dsp/iirfilter.h): the reference's own template, instantiated for the orders offered
+#include "dsp/iirfilter.h"
+namespace {
+struct IirBase { virtual ~IirBase() {} virtual float run(float s) = 0; };
+template<uint32_t O> struct IirImpl : IirBase { IIRFilter<float, O> f; IirImpl(const float* a, const float* b) : f(a, b) {} virtual float run(float s) { return f.run(s); } };
+}
+extern "C" {
+void* ref_iir_new(int32_t order, const float* a, const float* b)
+{
+    switch (order) {
+    case 2: return static_cast<IirBase*>(new IirImpl<2>(a, b));
+    case 3: return static_cast<IirBase*>(new IirImpl<3>(a, b));
+    case 4: return static_cast<IirBase*>(new IirImpl<4>(a, b));
+    case 5: return static_cast<IirBase*>(new IirImpl<5>(a, b));
+    case 6: return static_cast<IirBase*>(new IirImpl<6>(a, b));
+    case 7: return static_cast<IirBase*>(new IirImpl<7>(a, b));
+    case 8: return static_cast<IirBase*>(new IirImpl<8>(a, b));
+    }
+    return 0;
+}
+void ref_iir_free(void* h) { delete static_cast<IirBase*>(h); }
+void ref_iir_run(void* h, const float* in, int64_t n, float* out) { IirBase* f = static_cast<IirBase*>(h); for (int64_t k = 0; k < n; k++) out[k] = f->run(in[k]); }
+}

@@ -112,6 +112,12 @@ sdro_ssbtail* sdro_ssbtail_new(int32_t agc_active, int32_t agc_nb_samples, doubl
 void    sdro_ssbtail_free(sdro_ssbtail*);
 void    sdro_ssbtail_process(sdro_ssbtail*, const float* sideband, int64_t n, int16_t* audio);
 
+/* IIRFilter<float, Order> (sdrbase/dsp/iirfilter.h), Order 2..8 */
+typedef struct sdro_iir sdro_iir;
+sdro_iir* sdro_iir_new(int32_t order, const float* a, const float* b);
+void    sdro_iir_free(sdro_iir*);
+void    sdro_iir_run(sdro_iir*, const float* in, int64_t n, float* out);
+
 typedef struct sdro_fdecim sdro_fdecim;
 sdro_fdecim* sdro_fdecim_new(int log2_decim, int fcpos, int in_kind, int out_kind, int input_bits);
 void    sdro_fdecim_free(sdro_fdecim*);

@@ -158,3 +158,41 @@ void sdro_ssbtail_process(sdro_ssbtail* t, const float* sideband, int64_t n, int
         audio[k] = to_q16(demod * t->volume);
     }
 }
+
+/* ------------------------------------------------------------------ IIRFilter<float, Order> (sdrbase/dsp/iirfilter.h)
+ * Order 2 is the specialisation (:121-160): y = b0 s + b1 x0 + b2 x1 + a1 y0 + a2 y1, summed left to right.
+ * Other orders use the generic template (:59-105), whose setCoeffs stores `b` in m_a and `a` in m_b (sic) and whose run()
+ * walks i = Order .. 1:  y = m_b[0] s;  y += m_b[i] x[i-1] + m_a[i] y[i-1]. */
+struct sdro_iir { int order; float ma[9], mb[9], x[8], y[8]; };
+
+sdro_iir* sdro_iir_new(int32_t order, const float* a, const float* b)
+{
+    sdro_iir* f = (sdro_iir*)calloc(1, sizeof *f);
+    f->order = order;
+    for (int i = 0; i <= order; i++) {
+        if (order == 2) { f->ma[i] = a[i]; f->mb[i] = b[i]; }
+        else { f->ma[i] = b[i]; f->mb[i] = a[i]; }
+    }
+    return f;
+}
+void sdro_iir_free(sdro_iir* f) { free(f); }
+void sdro_iir_run(sdro_iir* f, const float* in, int64_t n, float* out)
+{
+    const int O = f->order;
+    for (int64_t k = 0; k < n; k++) {
+        const float s = in[k];
+        float y;
+        if (O == 2) {
+            y = f->mb[0] * s + f->mb[1] * f->x[0] + f->mb[2] * f->x[1] + f->ma[1] * f->y[0] + f->ma[2] * f->y[1];
+            f->x[1] = f->x[0]; f->x[0] = s; f->y[1] = f->y[0]; f->y[0] = y;
+        } else {
+            y = f->mb[0] * s;
+            for (int i = O; i > 0; i--) {
+                y += f->mb[i] * f->x[i - 1] + f->ma[i] * f->y[i - 1];
+                if (i > 1) { f->x[i - 1] = f->x[i - 2]; f->y[i - 1] = f->y[i - 2]; }
+            }
+            f->x[0] = s; f->y[0] = y;
+        }
+        out[k] = y;
+    }
+}

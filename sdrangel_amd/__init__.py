@@ -141,6 +141,10 @@ def lib() -> C.CDLL:
         "sdrx_audiotail_feed": (C.c_int, [vp, vp, vp, vp]),
         "sdrx_audiotail_feed_dev": (C.c_int, [vp, vp, vp, vp]),
         "sdrx_audiotail_sync": (C.c_int, [vp]),
+        "sdrx_iir_create": (C.c_int, [pp, C.c_int, i32, vp]),
+        "sdrx_iir_destroy": (C.c_int, [vp]),
+        "sdrx_iir_reset": (C.c_int, [vp]),
+        "sdrx_iir_feed": (C.c_int, [vp, vp, vp, vp]),
         "sdrx_firbank_create": (C.c_int, [pp, C.c_int, i32, vp]),
         "sdrx_firbank_destroy": (C.c_int, [vp]),
         "sdrx_firbank_feed": (C.c_int, [vp, vp, vp, vp]),
@@ -651,6 +655,44 @@ class AudioTail:
         ns = (C.c_int64 * self.n_ch)(*[x.size // 2 for x in ins])
         _check(lib().sdrx_audiotail_feed(self._h, pi, ns, po), "sdrx_audiotail_feed")
         return [o[: x.size // 2] for o, x in zip(outs, ins)]
+
+
+class IirCfg(C.Structure):
+    _fields_ = [("order", C.c_int32), ("a", C.c_float * 9), ("b", C.c_float * 9)]
+
+
+class IirBank:
+    """IIRFilter<float, Order> (sdrbase/dsp/iirfilter.h), one filter per channel"""
+
+    def __init__(self, specs, device: int = 0):
+        """specs: list of (order, a, b)"""
+        self.n_ch = len(specs)
+        arr = (IirCfg * self.n_ch)()
+        for i, (o, a, b) in enumerate(specs):
+            arr[i].order = o
+            for j in range(o + 1):
+                arr[i].a[j] = a[j]; arr[i].b[j] = b[j]
+        self._h = C.c_void_p()
+        _check(lib().sdrx_iir_create(C.byref(self._h), device, self.n_ch, arr), "sdrx_iir_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sdrx_iir_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def reset(self):
+        _check(lib().sdrx_iir_reset(self._h), "sdrx_iir_reset")
+
+    def feed(self, per_channel):
+        ins = [np.ascontiguousarray(x, dtype=np.float32) for x in per_channel]
+        outs = [np.zeros(max(x.size, 1), np.float32) for x in ins]
+        pi = (C.c_void_p * self.n_ch)(*[x.ctypes.data for x in ins])
+        po = (C.c_void_p * self.n_ch)(*[x.ctypes.data for x in outs])
+        ns = (C.c_int64 * self.n_ch)(*[x.size for x in ins])
+        _check(lib().sdrx_iir_feed(self._h, pi, ns, po), "sdrx_iir_feed")
+        return [o[: x.size] for o, x in zip(outs, ins)]
 
 
 class IqImbalance:

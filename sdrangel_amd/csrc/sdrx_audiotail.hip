@@ -353,3 +353,132 @@ int sdrx_audiotail_sync(sdrx_audiotail_t* h)
 }
 
 } // extern "C"
+
+
+/* =====================================================================================================================
+ * sdrx_iir_* -- IIRFilter<float, Order> (sdrbase/dsp/iirfilter.h; users: FilterMbe's 2nd-order low/high pass pair,
+ * sdrbase/dsp/filtermbe.h:76-77).  A recursive filter is serial along time by nature; one lane per channel, the
+ * reference's operation order (order 2: the specialisation :150-160; other orders: the generic template :88-105, including
+ * its swapped coefficient copy :78-81), float multiply and add kept separate.
+ * ===================================================================================================================== */
+namespace {
+struct IirChan { int order; float ma[9], mb[9], x[8], y[8]; };
+struct IirJob { const float* in; float* out; long n; };
+
+__global__ __launch_bounds__(64)
+void iir_kernel(IirChan* __restrict__ chans, const IirJob* __restrict__ jobs, int n_ch)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= n_ch) return;
+    IirChan s = chans[c];
+    const IirJob jb = jobs[c];
+    const int O = s.order;
+    for (long k = 0; k < jb.n; k++) {
+        const float v = jb.in[k];
+        float y;
+        if (O == 2) {
+            y = s.mb[0] * v + s.mb[1] * s.x[0] + s.mb[2] * s.x[1] + s.ma[1] * s.y[0] + s.ma[2] * s.y[1];
+            s.x[1] = s.x[0]; s.x[0] = v; s.y[1] = s.y[0]; s.y[0] = y;
+        } else {
+            y = s.mb[0] * v;
+#pragma unroll
+            for (int i = 8; i > 0; i--) {
+                if (i > O) continue;
+                y += s.mb[i] * s.x[i - 1] + s.ma[i] * s.y[i - 1];
+                if (i > 1) { s.x[i - 1] = s.x[i - 2]; s.y[i - 1] = s.y[i - 2]; }
+            }
+            s.x[0] = v; s.y[0] = y;
+        }
+        jb.out[k] = y;
+    }
+    chans[c] = s;
+}
+} // namespace
+
+struct sdrx_iir {
+    int device = 0, n_ch = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::vector<IirChan> init;
+    IirChan* d_chan = nullptr; IirJob* d_jobs = nullptr; IirJob* h_jobs = nullptr; hipEvent_t jobs_ev = nullptr;
+    std::vector<DevBuf> d_in, d_out;
+};
+
+extern "C" {
+
+int sdrx_iir_create(sdrx_iir_t** out, int device, int32_t n_ch, const sdrx_iir_cfg* cfg)
+{
+    if (!out || n_ch <= 0 || !cfg) { set_error("sdrx_iir_create: bad argument"); return SDRX_EINVAL; }
+    *out = nullptr;
+    for (int c = 0; c < n_ch; c++) if (cfg[c].order < 2 || cfg[c].order > 8) { set_error("sdrx_iir_create: order 2..8"); return SDRX_EINVAL; }
+    int rc = check_device(device); if (rc) return rc;
+    SDRX_HIP(hipSetDevice(device));
+    sdrx_iir* h = new (std::nothrow) sdrx_iir;
+    if (!h) return SDRX_ENOMEM;
+    h->device = device; h->n_ch = n_ch; h->init.resize((size_t)n_ch); h->d_in.resize((size_t)n_ch); h->d_out.resize((size_t)n_ch);
+    for (int c = 0; c < n_ch; c++) {
+        IirChan& s = h->init[(size_t)c];
+        std::memset(&s, 0, sizeof s);
+        s.order = cfg[c].order;
+        for (int i = 0; i <= s.order; i++) {
+            if (s.order == 2) { s.ma[i] = cfg[c].a[i]; s.mb[i] = cfg[c].b[i]; }
+            else { s.ma[i] = cfg[c].b[i]; s.mb[i] = cfg[c].a[i]; }              // iirfilter.h:78-81 (sic)
+        }
+    }
+    hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) { h->stream = h->own_stream; e = hipMalloc(reinterpret_cast<void**>(&h->d_chan), sizeof(IirChan) * (size_t)n_ch); }
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_jobs), sizeof(IirJob) * (size_t)n_ch);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->h_jobs), sizeof(IirJob) * (size_t)n_ch, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->jobs_ev, hipEventDisableTiming);
+    if (e != hipSuccess) { sdrx_iir_destroy(h); return hip_fail(e, "sdrx_iir_create", __FILE__, __LINE__); }
+    *out = h;
+    return sdrx_iir_reset(h);
+}
+
+int sdrx_iir_destroy(sdrx_iir_t* h)
+{
+    if (!h) return SDRX_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->d_chan) (void)hipFree(h->d_chan);
+    if (h->d_jobs) (void)hipFree(h->d_jobs);
+    if (h->h_jobs) (void)hipHostFree(h->h_jobs);
+    if (h->jobs_ev) (void)hipEventDestroy(h->jobs_ev);
+    for (auto& b : h->d_in) b.release();
+    for (auto& b : h->d_out) b.release();
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return SDRX_OK;
+}
+
+int sdrx_iir_reset(sdrx_iir_t* h)
+{
+    if (!h) return SDRX_EINVAL;
+    SDRX_HIP(hipSetDevice(h->device));
+    SDRX_HIP(hipMemcpyAsync(h->d_chan, h->init.data(), sizeof(IirChan) * (size_t)h->n_ch, hipMemcpyHostToDevice, h->stream));
+    SDRX_HIP(hipStreamSynchronize(h->stream));
+    return SDRX_OK;
+}
+
+int sdrx_iir_feed(sdrx_iir_t* h, const float* const* in, const int64_t* n, float* const* out)
+{
+    if (!h || !in || !n || !out) { set_error("sdrx_iir_feed: bad argument"); return SDRX_EINVAL; }
+    SDRX_HIP(hipSetDevice(h->device));
+    SDRX_HIP(hipEventSynchronize(h->jobs_ev));
+    for (int c = 0; c < h->n_ch; c++) {
+        if (n[c] < 0 || (n[c] > 0 && (!in[c] || !out[c]))) { set_error("sdrx_iir_feed: bad channel argument"); return SDRX_EINVAL; }
+        int rc = h->d_in[(size_t)c].reserve((size_t)(n[c] > 0 ? n[c] : 1) * 4); if (rc) return rc;
+        rc = h->d_out[(size_t)c].reserve((size_t)(n[c] > 0 ? n[c] : 1) * 4); if (rc) return rc;
+        if (n[c]) SDRX_HIP(hipMemcpyAsync(h->d_in[(size_t)c].p, in[c], (size_t)n[c] * 4, hipMemcpyHostToDevice, h->stream));
+        h->h_jobs[c] = IirJob{ static_cast<const float*>(h->d_in[(size_t)c].p), static_cast<float*>(h->d_out[(size_t)c].p), (long)n[c] };
+    }
+    SDRX_HIP(hipMemcpyAsync(h->d_jobs, h->h_jobs, sizeof(IirJob) * (size_t)h->n_ch, hipMemcpyHostToDevice, h->stream));
+    SDRX_HIP(hipEventRecord(h->jobs_ev, h->stream));
+    hipLaunchKernelGGL(iir_kernel, dim3((unsigned)((h->n_ch + 63) / 64)), dim3(64), 0, h->stream, h->d_chan, h->d_jobs, h->n_ch);
+    SDRX_HIP(hipGetLastError());
+    for (int c = 0; c < h->n_ch; c++)
+        if (n[c]) SDRX_HIP(hipMemcpyAsync(out[c], h->d_out[(size_t)c].p, (size_t)n[c] * 4, hipMemcpyDeviceToHost, h->stream));
+    SDRX_HIP(hipStreamSynchronize(h->stream));
+    return SDRX_OK;
+}
+
+} // extern "C"

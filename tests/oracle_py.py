@@ -286,3 +286,23 @@ class AudioTailOracle:
         out = np.zeros(max(x.size // 2, 1), np.int16)
         (self.L.sdro_nfmtail_process if self.kind == 0 else self.L.sdro_ssbtail_process)(self.h, x.ctypes.data, x.size // 2, out.ctypes.data)
         return out[: x.size // 2]
+
+
+class Iir:
+    """oracle IIRFilter<float, Order> (oracle/sdro_audio.c)"""
+
+    def __init__(self, order, a, b):
+        self.L = lib()
+        self.L.sdro_iir_new.restype = C.c_void_p; self.L.sdro_iir_new.argtypes = [C.c_int32, C.c_void_p, C.c_void_p]
+        self.L.sdro_iir_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]; self.L.sdro_iir_free.argtypes = [C.c_void_p]
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        self.h = self.L.sdro_iir_new(order, a.ctypes.data, b.ctypes.data)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.sdro_iir_free(self.h); self.h = None
+
+    def run(self, x):
+        x = np.ascontiguousarray(x, np.float32); out = np.zeros(max(x.size, 1), np.float32)
+        self.L.sdro_iir_run(self.h, x.ctypes.data, x.size, out.ctypes.data)
+        return out[: x.size]

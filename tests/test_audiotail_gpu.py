@@ -67,3 +67,28 @@ def test_forty_channels_share_a_launch():
     got = g.feed(xs)
     for c in range(40):
         assert np.array_equal(got[c], orc.AudioTailOracle(**cfgs[c]).feed(xs[c])), c
+
+
+IIR_SPECS = [
+    # FilterMbe's pair (sdrbase/dsp/filtermbe.cpp): 2nd-order low pass / high pass, a = feedback, b = feed-forward
+    (2, [1.0, 1.5610180758, -0.6413515381], [0.0200833656, 0.0401667311, 0.0200833656]),
+    (2, [1.0, 1.9111970674, -0.9149758348], [0.9565432255, -1.9130864510, 0.9565432255]),
+    (3, [0.01, 0.03, 0.03, 0.01], [1.0, 0.9, -0.5, 0.1]),
+    (4, [0.004, 0.016, 0.024, 0.016, 0.004], [1.0, 0.7, -0.3, 0.05, -0.01]),
+    (8, [0.2, 0.1, 0.05, 0.02, 0.01, 0.0, -0.01, 0.0, 0.005], [1.0, 0.3, -0.2, 0.1, -0.05, 0.02, -0.01, 0.005, -0.002]),
+]
+
+
+def test_iir_bank_matches_oracle_bitwise():
+    """sdrx_iir_*: IIRFilter<float, Order>, order 2 (specialisation) and the generic template (swapped coefficient copy),
+    ragged feeds, state carried; float results bit-identical to the oracle (pinned to the reference's template)"""
+    rng = np.random.default_rng(4)
+    specs = IIR_SPECS * 15                                     # 75 channels: more than one wave
+    g = sa.IirBank(specs)
+    os_ = [orc.Iir(*s) for s in specs]
+    for sizes in ([1], [0], [5000], [33], [12000]):
+        xs = [rng.standard_normal(sizes[0] + (c % 3)).astype(np.float32) * 1000 for c in range(len(specs))]
+        got = g.feed(xs)
+        for c in range(len(specs)):
+            want = os_[c].run(xs[c])
+            assert got[c].size == want.size and np.array_equal(got[c].view(np.uint32), want.view(np.uint32)), (c, sizes)

@@ -241,6 +241,23 @@ def test_nfm_and_ssb_audio_tails_vs_reference_members():
             assert np.array_equal(o.feed(seg), want), (i, a, b)
 
 
+def test_iir_filter_vs_reference_template():
+    """oracle IIR vs IIRFilter<float, Order> instantiated from sdrbase/dsp/iirfilter.h for Order 2..8, bit-identical"""
+    from tests.test_audiotail_gpu import IIR_SPECS
+    R = C.CDLL(REF)
+    R.ref_iir_new.restype = C.c_void_p; R.ref_iir_new.argtypes = [C.c_int32, C.c_void_p, C.c_void_p]
+    R.ref_iir_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    rng = np.random.default_rng(12)
+    extra = [(o, list(rng.uniform(-0.2, 0.2, o + 1)), [1.0] + list(rng.uniform(-0.3, 0.3, o))) for o in (5, 6, 7)]
+    for o, a, b in IIR_SPECS + extra:
+        a32 = np.ascontiguousarray(a, np.float32); b32 = np.ascontiguousarray(b, np.float32)
+        h = R.ref_iir_new(o, a32.ctypes.data, b32.ctypes.data); f = orc.Iir(o, a, b)
+        for n in (1, 7, 4000):
+            x = (rng.standard_normal(n) * 500).astype(np.float32); want = np.zeros(n, np.float32)
+            R.ref_iir_run(h, x.ctypes.data, n, want.ctypes.data)
+            assert np.array_equal(f.run(x).view(np.uint32), want.view(np.uint32)), (o, n)
+
+
 def test_sample_sink_fifo_mirror_vs_the_real_class():
     """sdrx_fifo_* against the reference's SampleSinkFifo (QObject, built with moc into oracle/_ref/libsdrref_qt.so): 2400
     random write / write(bytes) / read / readBegin / readCommit operations incl. overflow and underflow; the same child also
