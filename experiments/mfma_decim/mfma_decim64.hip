@@ -68,6 +68,8 @@ __device__ __forceinline__ uint32_t pk_h2(float a, float b)
     return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));              // exact: both values are f16-representable integers
 }
 
+template<int NS> struct TileRegs { h8 BaL[NS][4], BbL[NS][4], BaH[NS][4], BbH[NS][4]; f4 ev[NS][4], acc[NS][4], acch[NS][4]; };
+
 template<int POST>
 __global__ __launch_bounds__(64)
 void decim64_mfma_kernel(const uint4* __restrict__ hist,      // CHUNK samples: tail of the previous call
@@ -149,12 +151,9 @@ void decim64_mfma_kernel(const uint4* __restrict__ hist,      // CHUNK samples: 
         }
 
         // the stages, 6 down to 1; a group of stages = loads, then MFMAs, then epilogues
-        auto group = [&](auto lo_c, auto hi_c) {
-            constexpr int SLO = decltype(lo_c)::value, SHI = decltype(hi_c)::value;      // stages SHI down to SLO
-            // per stage: TILES * NCOMP tile-components; at most 4 (stage 1)
-            h8 BaL[SHI - SLO + 1][4], BbL[SHI - SLO + 1][4], BaH[SHI - SLO + 1][4], BbH[SHI - SLO + 1][4];
-            f4 ev[SHI - SLO + 1][4], acc[SHI - SLO + 1][4], acch[SHI - SLO + 1][4];
-            // -- loads
+        auto loads = [&](auto lo_c, auto hi_c, auto& R) {
+            constexpr int SLO = decltype(lo_c)::value, SHI = decltype(hi_c)::value;      // stages SLO .. SHI
+            auto& BaL = R.BaL; auto& BbL = R.BbL; auto& BaH = R.BaH; auto& BbH = R.BbH; auto& ev = R.ev;
             static_for<SLO, SHI + 1>([&](auto sc) {
                 constexpr int s = decltype(sc)::value, si = s - SLO;
                 constexpr int NOUT = S >> s;
@@ -179,7 +178,10 @@ void decim64_mfma_kernel(const uint4* __restrict__ hist,      // CHUNK samples: 
                     ev[si][tc] = *reinterpret_cast<const f4*>(lds + eA(s, MERGED ? 0 : cfix) + cb + e_phys(base + 4 * g) * 4);
                 });
             });
-            // -- matrix cores
+        };
+        auto mmas = [&](auto lo_c, auto hi_c, auto& R) {
+            constexpr int SLO = decltype(lo_c)::value, SHI = decltype(hi_c)::value;
+            auto& BaL = R.BaL; auto& BbL = R.BbL; auto& BaH = R.BaH; auto& BbH = R.BbH; auto& acc = R.acc; auto& acch = R.acch;
             static_for<SLO, SHI + 1>([&](auto sc) {
                 constexpr int s = decltype(sc)::value, si = s - SLO;
                 constexpr int NOUT = S >> s;
@@ -196,8 +198,10 @@ void decim64_mfma_kernel(const uint4* __restrict__ hist,      // CHUNK samples: 
                     } else acch[si][tc] = z;
                 });
             });
-            // -- carry of the arrays these stages have just read (before the stages below overwrite their payload),
-            //    then epilogues: y, limb split, hand-over to the next stage's arrays
+        };
+        // carry of the arrays these stages have just read (before the stages below overwrite their payload)
+        auto carry = [&](auto lo_c, auto hi_c) {
+            constexpr int SLO = decltype(lo_c)::value, SHI = decltype(hi_c)::value;
             static_for<SLO, SHI + 1>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
                 constexpr int NL = n_limb(s);
@@ -214,6 +218,11 @@ void decim64_mfma_kernel(const uint4* __restrict__ hist,      // CHUNK samples: 
                     *reinterpret_cast<uint32_t*>(lds + stage_off(s) + comp_bytes(s) + dst) = v1;
                 }
             });
+        };
+        // epilogues: y, limb split, hand-over to the next stage's arrays
+        auto post = [&](auto lo_c, auto hi_c, auto& R) {
+            constexpr int SLO = decltype(lo_c)::value, SHI = decltype(hi_c)::value;
+            auto& acc = R.acc; auto& acch = R.acch; auto& ev = R.ev;
             static_for<SLO, SHI + 1>([&](auto sc) {
                 constexpr int s = SHI + SLO - decltype(sc)::value, si = s - SLO;         // highest stage first
                 constexpr int NOUT = S >> s;
@@ -252,8 +261,19 @@ void decim64_mfma_kernel(const uint4* __restrict__ hist,      // CHUNK samples: 
                 });
             });
         };
-        group(std::integral_constant<int, 3>{}, std::integral_constant<int, L>{});     // stages 6, 5, 4, 3: four merged tiles
-        group(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});     // stage 2 (two tiles) and stage 1 (four)
+        // group A = stages 6..3 (four merged tiles), group B = stages 2 (two tiles) and 1 (four).  B's loads are issued before
+        // A's epilogue stores so that A's VALU work overlaps B's LDS latency and matrix work.
+        const std::integral_constant<int, 1> c1{}; const std::integral_constant<int, 2> c2{};
+        const std::integral_constant<int, 3> c3{}; const std::integral_constant<int, L> cL{};
+        TileRegs<L - 2> RA; TileRegs<2> RB;
+        loads(c3, cL, RA);
+        mmas(c3, cL, RA);
+        loads(c1, c2, RB);
+        carry(c3, cL);
+        post(c3, cL, RA);
+        mmas(c1, c2, RB);
+        carry(c1, c2);
+        post(c1, c2, RB);
 
         const long sub6 = it - (L - 1);                                                  // the sub-chunk stage 6 has just finished
         if (sub6 >= first && sub6 < last && lane < (S >> L)) {

@@ -150,8 +150,9 @@ __device__ __forceinline__ void stage_i32_split(const int* __restrict__ oI, cons
             }
         });
     });
-    if constexpr (SPLIT >= 2) { acc[0] += __shfl_xor(acc[0], 1); acc[1] += __shfl_xor(acc[1], 1); }
-    if constexpr (SPLIT >= 4) { acc[0] += __shfl_xor(acc[0], 2); acc[1] += __shfl_xor(acc[1], 2); }
+    // partner lanes sit inside one quad: DPP quad_perm (a VALU operand modifier), not ds_bpermute (an LDS round trip)
+    if constexpr (SPLIT >= 2) { acc[0] += __builtin_amdgcn_mov_dpp(acc[0], 0xB1, 0xf, 0xf, true); acc[1] += __builtin_amdgcn_mov_dpp(acc[1], 0xB1, 0xf, 0xf, true); }
+    if constexpr (SPLIT >= 4) { acc[0] += __builtin_amdgcn_mov_dpp(acc[0], 0x4E, 0xf, 0xf, true); acc[1] += __builtin_amdgcn_mov_dpp(acc[1], 0x4E, 0xf, 0xf, true); }
     // centre tap e[k - 15]: own component for centre mode, the other one (signed) for inf/sup
     const int* e = (MODE == MODE_CEN) ? (comp ? eQ : eI) : (comp ? eI : eQ);
     const int cbase = HIST + 2 * p - CD;
@@ -206,12 +207,18 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
     for (int i = lane; i < df_lds_dwords(L); i += 64) lds[i] = 0;
 
     QT pre[LPT];
+    // A sub-chunk is either wholly history (sub < 0) or wholly input: the source is chosen with a wave-uniform (scalar)
+    // branch and the only per-lane test is a 32-bit compare against the quads left in the stream.
     auto fetch = [&](long sub) {
+        const QT* __restrict__ src;
+        long left;
+        if (sub < 0) { src = hist + (sub + DF_WARM) * (S / 4); left = S / 4; }
+        else { src = in + sub * (S / 4); left = n_in4 - sub * (S / 4); }
+        const int lim = left > S / 4 ? S / 4 : (int)left;
 #pragma unroll
         for (int j = 0; j < LPT; j++) {
-            const long g = sub * (S / 4) + j * 64 + lane;         // quad index; sub < 0: history
-            if (g < 0) pre[j] = hist[g + DF_CHUNK / 4];
-            else pre[j] = g < n_in4 ? in[g] : Quad<U8>::zero();
+            const int q = j * 64 + lane;
+            pre[j] = q < lim ? src[q] : Quad<U8>::zero();
         }
     };
     fetch(first - DF_WARM);
@@ -273,7 +280,9 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
                     ed[HIST + p] = y[0]; od[HIST + p] = y[1];
                 } else {
                     // partner component sits SPLIT lanes up; lanes with comp == 0 and slice 0 store
-                    const int q0 = __shfl_down(y[0], SPLIT), q1 = __shfl_down(y[1], SPLIT);
+                    // lane + SPLIT: quad_perm [1,2,3,3] / [2,3,3,3] inside a quad, row_shl:4 across quads (only lanes whose partner exists store)
+                    constexpr int DN = SPLIT == 1 ? 0xF9 : SPLIT == 2 ? 0xFE : 0x104;
+                    const int q0 = __builtin_amdgcn_mov_dpp(y[0], DN, 0xf, 0xf, true), q1 = __builtin_amdgcn_mov_dpp(y[1], DN, 0xf, 0xf, true);
                     if (live && comp == 0 && (lane % SPLIT) == 0) {
                         const long base = sub * NOUT + 2 * p;
                         if (base < n_out)     out[base]     = pack_iq(y[0] >> post, q0 >> post);
@@ -292,25 +301,32 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
         if (live && lane == 0 && ((sub + 1) % (DF_CHUNK / S) == 0 || sub + 1 == last))
             ovf_flags[sub / (DF_CHUNK / S)] = bad ? 1u : 0u;
 
-        // carry: the last HD dwords of every array become the next sub-chunk's history
+        // carry: the last HD dwords of every array become the next sub-chunk's history.  Every stage's tail is read first
+        // (the regions overlap when ND < HD), then everything is written: one LDS round trip for all stages, not one each.
+        uint32_t keep[L][2];
         static_for<1, L + 1>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             constexpr int HD = df_in16(s) ? HIST / 2 : HIST;
             constexpr int ND = df_in16(s) ? (DF_SUB >> (s + 1)) : (DF_SUB >> s);      // payload dwords per array
-            uint32_t* a = lds + df_off(s);
-            // 4 arrays x HD dwords; read everything first (the regions overlap when ND < HD)
-            constexpr int TOT = 4 * HD, PER = (TOT + 63) / 64;
-            uint32_t tmp[PER];
+            constexpr int TOT = 4 * HD, PER = TOT / 64;
+            static_assert(TOT % 64 == 0, "four arrays x 16 or 32 history dwords: a whole number of wave-wide accesses, no lane test");
+            const uint32_t* a = lds + df_off(s);
 #pragma unroll
             for (int q = 0; q < PER; q++) {
                 const int i = q * 64 + lane;
-                tmp[q] = i < TOT ? a[(i / HD) * df_arr(s) + ND + (i % HD)] : 0u;
+                keep[s - 1][q] = a[(i / HD) * df_arr(s) + ND + (i % HD)];
             }
-            __syncthreads();
+        });
+        __syncthreads();
+        static_for<1, L + 1>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr int HD = df_in16(s) ? HIST / 2 : HIST;
+            constexpr int TOT = 4 * HD, PER = TOT / 64;
+            uint32_t* a = lds + df_off(s);
 #pragma unroll
             for (int q = 0; q < PER; q++) {
                 const int i = q * 64 + lane;
-                if (i < TOT) a[(i / HD) * df_arr(s) + (i % HD)] = tmp[q];
+                a[(i / HD) * df_arr(s) + (i % HD)] = keep[s - 1][q];
             }
         });
         __syncthreads();

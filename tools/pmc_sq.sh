@@ -5,8 +5,8 @@ run() { # name counters... -- cmd
   name=$1; shift; ctrs=$1; shift
   timeout -k 10 200 rocprofv3 --pmc $ctrs --output-format csv -d $O/$name -- "$@" > $O/$name.log 2>&1
 }
-D="python3 bench.py --no-cpu --steps 2 --warmup 1"
-C="python3 bench.py --workload chan32 --batch 67108864 --no-cpu --steps 2 --warmup 1"
+D="python3 bench.py --workload decim64 --no-cpu --steps 2 --warmup 1"
+C="python3 bench.py --workload chan32 --no-cpu --steps 2 --warmup 1"
 run d1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU" $D
 run d2 "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES" $D
 run c1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU" $C
