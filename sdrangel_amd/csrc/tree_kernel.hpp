@@ -177,9 +177,22 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
         for (int l = 0; l < st.n_levels; l++) {
             const TkLevel lv = st.lv[l];
             const int njobs = lv.n_nodes << lv.jobs_log2;
-            for (int i = tid; i < lv.arr_cnt * 16; i += NT) {                      // history of the arrays this level produces
-                const uint32_t a = lds[st.arr_tab + lv.arr_base + (i >> 4)];
-                lds[(a & 0xffffu) + (i & 15)] = lds[(a >> 16) + (i & 15)];
+            {   // ONE pass over the per-array table, before the jobs: (1) history of the arrays this level PRODUCES goes in
+                // front of their windows, (2) the arrays this level READS are complete and only read from here on, so their
+                // last 16 dwords are kept for the next chunk now (this used to be a second dependent LDS round trip behind
+                // the jobs of every level).
+                const int sb = l == 0 ? 0 : st.lv[l - 1].arr_base, sc = l == 0 ? st.root_arr_cnt : st.lv[l - 1].arr_cnt;
+                const int n_restore = lv.arr_cnt * 16, n_all = n_restore + sc * 16;
+                for (int i = tid; i < n_all; i += NT) {
+                    if (i < n_restore) {
+                        const uint32_t a = lds[st.arr_tab + lv.arr_base + (i >> 4)];
+                        lds[(a & 0xffffu) + (i & 15)] = lds[(a >> 16) + (i & 15)];
+                    } else {
+                        const int k = i - n_restore;
+                        const uint32_t a = lds[st.arr_tab + sb + (k >> 4)];
+                        lds[(a >> 16) + (k & 15)] = lds[(a & 0xffffu) + lv.in_len - 16 + (k & 15)];
+                    }
+                }
             }
             // One job = (table entry, R consecutive outputs).  R = 8 while that still gives every lane a job; narrow levels
             // (few entries, short chunks: the bottom of every subtree) drop to R = 4 or 2 so that the lanes stay busy --
@@ -295,7 +308,9 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                         for (int si = (int)o1.z; si >= 0; ) {
                             const TkSink sk = sinks[si];
                             const long rel = abs0 - sk.lo, span = sk.hi - sk.lo;
-                            uint32_t* dst = sk.ptr + (abs0 - sk.base);
+                            // the sink pointers come out of a table: tell the compiler they are global memory (flat_store otherwise)
+                            typedef uint32_t __attribute__((address_space(1))) gu32;
+                            gu32* dst = (gu32*)(sk.ptr + (abs0 - sk.base));
                             if (rel >= 0 && rel + R <= span) {                     // whole job in range: no per-sample guards
 #pragma unroll
                                 for (int r = 0; r < R; r++)
@@ -318,13 +333,6 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
             if (lv.r_log2 == 3)      for (int j = tid; j < njobs; j += NT) job(std::integral_constant<int, 8>{}, j);
             else if (lv.r_log2 == 2) for (int j = tid; j < njobs; j += NT) job(std::integral_constant<int, 4>{}, j);
             else                     for (int j = tid; j < njobs; j += NT) job(std::integral_constant<int, 2>{}, j);
-            {   // the arrays this level READ are complete and still intact: keep their last 16 dwords for the next chunk
-                const int sb = l == 0 ? 0 : st.lv[l - 1].arr_base, sc = l == 0 ? st.root_arr_cnt : st.lv[l - 1].arr_cnt;
-                for (int i = tid; i < sc * 16; i += NT) {
-                    const uint32_t a = lds[st.arr_tab + sb + (i >> 4)];
-                    lds[(a >> 16) + (i & 15)] = lds[(a & 0xffffu) + lv.in_len - 16 + (i & 15)];
-                }
-            }
             __syncthreads();
         }
     }

@@ -36,7 +36,8 @@ for wl, batch, alg in (("decim64", b_decim, 4.0625), ("chan32", b_chan, 4.125), 
                                "fetch_size_kib_raw": sum(fv) / len(fv) if fv else None,
                                "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                                "hbm_bytes_per_launch": (rd or 0) + (wr or 0),
-                               "hbm_bytes_per_step": ((2 * 1024 * sum(fv)) + 1024 * sum(wv)) / STEPS,
+                               # a bank feed = `passes` tree_kernel launches (cfg 3: two); the decimator is one launch per step
+                               "hbm_bytes_per_step": ((rd or 0) + (wr or 0)) * (2 if (wl == "chan32" and k.startswith("tree_kernel")) else 1),
                                "algorithmic_bytes_per_launch": alg * batch})
 json.dump(out, open(os.path.join("profiles", f"{tag}_traffic.json"), "w"), indent=1)
 for e in out["kernels"]:
