@@ -100,16 +100,22 @@ void decim64_mfma_kernel(const uint4* __restrict__ hist,      // CHUNK samples: 
         }
     }
 
-    uint4 pre[4];
-    auto fetch = [&](long sub) {
+    // Input prefetch, TWO sub-chunks ahead.  A wave has 4 KB per sub-chunk in flight; with one sub-chunk of look-ahead the
+    // kernel ran at (resident waves x 4 KB) / (loaded HBM latency) whatever the compute structure (three variants, same rate).
+    uint4 pre[4], pre2[4];
+    auto fetch = [&](long sub, uint4 (&dst)[4]) {
+        const uint4* __restrict__ src; long left;                    // wave-uniform: a sub-chunk is wholly history or wholly input
+        if (sub < 0) { src = hist + (sub + WARM) * (S / 4); left = S / 4; }
+        else { src = in + sub * (S / 4); left = n_in4 - sub * (S / 4); }
+        const int lim = left > S / 4 ? S / 4 : (int)left;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const long q4 = sub * (S / 4) + j * 64 + lane;          // quad index; sub < 0: history
-            if (q4 < 0) pre[j] = hist[q4 + CHUNK / 4];
-            else pre[j] = q4 < n_in4 ? in[q4] : make_uint4(0, 0, 0, 0);
+            const int q = j * 64 + lane;
+            dst[j] = q < lim ? src[q] : make_uint4(0, 0, 0, 0);
         }
     };
-    fetch(first - WARM);
+    fetch(first - WARM + 1, pre2);
+    fetch(first - WARM, pre);
     bool bad = false;
     __syncthreads();
 
@@ -144,7 +150,9 @@ void decim64_mfma_kernel(const uint4* __restrict__ hist,      // CHUNK samples: 
                 auto ck = [&](uint32_t w) { chk |= __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, w) + bias)); };
                 ck(v.x); ck(v.y); ck(v.z); ck(v.w);
             }
-            if (it + 1 < last) fetch(it + 1);
+#pragma unroll
+            for (int j = 0; j < 4; j++) pre[j] = pre2[j];                // it + 1 moves up; it + 2 is requested now
+            if (it + 2 < last) fetch(it + 2, pre2);
             if (!bad && __any((chk & 0xf000f000u) != 0)) bad = true;
             if (it >= first && lane == 0 && ((it + 1) % (CHUNK / S) == 0 || it + 1 == last))
                 flags[it / (CHUNK / S)] = bad ? 1u : 0u;
@@ -261,16 +269,16 @@ void decim64_mfma_kernel(const uint4* __restrict__ hist,      // CHUNK samples: 
                 });
             });
         };
-        // group A = stages 6..3 (four merged tiles), group B = stages 2 (two tiles) and 1 (four).  B's loads are issued before
-        // A's epilogue stores so that A's VALU work overlaps B's LDS latency and matrix work.
+        // group A = stages 6..3 (four merged tiles), group B = stage 2 (two tiles) and stage 1 (four).  (Issuing B's loads before
+        // A's epilogue stores was tried: 224 instead of 146 VGPRs, one wave per SIMD fewer, same rate.)
         const std::integral_constant<int, 1> c1{}; const std::integral_constant<int, 2> c2{};
         const std::integral_constant<int, 3> c3{}; const std::integral_constant<int, L> cL{};
         TileRegs<L - 2> RA; TileRegs<2> RB;
         loads(c3, cL, RA);
         mmas(c3, cL, RA);
-        loads(c1, c2, RB);
         carry(c3, cL);
         post(c3, cL, RA);
+        loads(c1, c2, RB);
         mmas(c1, c2, RB);
         carry(c1, c2);
         post(c1, c2, RB);
