@@ -263,6 +263,38 @@ int sdrx_audiotail_feed_dev(sdrx_audiotail_t* h, const float* const* d_in, const
 int sdrx_audiotail_sync(sdrx_audiotail_t* h);
 
 /* ------------------------------------------------------------------------------------------
+ * The 24-bit sample build of the integer half-band path (the reference compiled with SDR_RX_SAMPLE_24BIT: dsptypes.h:24-34
+ * FixReal = qint32 and an 8-byte Sample; decimators.h:326-333, downchannelizer.h:78-81 IntHalfbandFilterEO<qint64,qint64,N>;
+ * decimation_shifts<24,InputBits>, decimators.h:62-185).  Samples in and out of these calls are {int32 re, int32 im}.
+ *   sdrx_decim24_*      Decimators<qint32, qint16, 24, {8,12,16}>::decimate{1..64}_{cen,inf,sup}: same call contract as
+ *                       sdrx_decim_process (whole groups, dropped tail, carried state); out_iq holds 2 x int32 per sample
+ *   sdrx_chan24_bank_*  N DownChannelizers on a 24-bit stream: any feed length, carried phase, final `/= (1 << n)`;
+ *                       sdrx_chan24_bank_read returns what the LAST feed produced for the channel
+ * Exact (incl. the build's 32-bit wrap of the centre tap, inthalfbandfiltereo.h:818-827), plain 64-bit arithmetic, not tuned.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sdrx_decim24 sdrx_decim24_t;
+int sdrx_decim24_create(sdrx_decim24_t** h, int device, int log2_decim, int fcpos, int input_bits);
+int sdrx_decim24_destroy(sdrx_decim24_t* h);
+int sdrx_decim24_reset(sdrx_decim24_t* h);
+int sdrx_decim24_process(sdrx_decim24_t* h, const int16_t* iq, int32_t n_int16, int32_t* out_iq, int32_t* n_out_cplx);
+/* device pointers, asynchronous on the handle's stream (sdrx_decim24_sync waits): d_iq = n_cplx int16 pairs, d_out = room for
+ * (n_cplx >> log2) + 1 samples of 8 bytes; *n_out_cplx = samples this call produced (the phase carries) */
+int sdrx_decim24_process_dev(sdrx_decim24_t* h, const void* d_iq, int64_t n_cplx, void* d_out, int64_t* n_out_cplx);
+int sdrx_decim24_sync(sdrx_decim24_t* h);
+typedef struct sdrx_chan24_bank sdrx_chan24_bank_t;
+int sdrx_chan24_bank_create(sdrx_chan24_bank_t** h, int device, int32_t in_rate, int32_t n_ch, const int32_t* req_rate, const int32_t* req_fc);
+int sdrx_chan24_bank_destroy(sdrx_chan24_bank_t* h);
+int sdrx_chan24_bank_reset(sdrx_chan24_bank_t* h);
+int sdrx_chan24_bank_info(const sdrx_chan24_bank_t* h, int32_t ch, int32_t* n_stages, uint8_t* modes, int32_t* out_rate, int32_t* residual_ofs);
+int sdrx_chan24_bank_feed(sdrx_chan24_bank_t* h, const int32_t* iq, int64_t n_cplx);
+int64_t sdrx_chan24_bank_read(sdrx_chan24_bank_t* h, int32_t ch, int32_t* out_iq, int64_t cap);
+/* device pointers: feed n_cplx {int32,int32} from HBM, then look at each channel's output where it lies (valid until the
+ * next feed); asynchronous on the bank's stream, sdrx_chan24_bank_sync waits */
+int sdrx_chan24_bank_feed_dev(sdrx_chan24_bank_t* h, const void* d_iq, int64_t n_cplx);
+int sdrx_chan24_bank_out_dev(sdrx_chan24_bank_t* h, int32_t ch, const void** d_out, int64_t* n_cplx);
+int sdrx_chan24_bank_sync(sdrx_chan24_bank_t* h);
+
+/* ------------------------------------------------------------------------------------------
  * IIRFilter<float, Order> (sdrbase/dsp/iirfilter.h; FilterMbe's low/high-pass pair, filtermbe.h:76-77): N recursive
  * filters, one per channel, state carried across feeds.  `a` / `b` are the constructor's arguments in the reference's
  * meaning: order 2 = the specialisation (y = b0 s + b1 x0 + b2 x1 + a1 y0 + a2 y1); other orders = the generic template,

@@ -26,13 +26,14 @@ typedef struct {
     const int32_t* c;
     int mode;             /* 0 centre, 1 lower/inf (x j^(n+1)), 2 upper/sup (x (-j)^(n+1)) */
     int narrow;           /* 1: Sample (int16) flavour -- int16 negation and int16 store */
+    int wide;             /* 1: SDR_RX_SAMPLE_24BIT build: IntHalfbandFilterEO<qint64,qint64,N> -- int64 accumulators, int32 samples */
     uint32_t n;           /* inputs seen since construction (rotation phase = n & 3, parity = n & 1) */
     int32_t re[64], im[64];
 } hb_stage;
 
 static void hb_init(hb_stage* s, int order, int mode, int narrow)
 {
-    memset(s, 0, sizeof *s);
+    memset(s, 0, sizeof *s);            /* wide = 0: callers of the 24-bit flavour set it afterwards */
     s->order = order;
     s->c = order == 64 ? HB64 : HB48;
     s->mode = mode;
@@ -72,6 +73,24 @@ static inline int hb_push(hb_stage* s, int32_t* re, int32_t* im)
     if (!odd) return 0;
 
     const int N = s->order, P = N / 4;
+    if (s->wide) {
+        /* EOStorageType = AccuType = qint64 (decimators.h:326-333, downchannelizer.h:78-81): the pair sums and products are
+         * int64; the centre tap is `((int32_t) x) << 11` -- an INT shift, i.e. it wraps at 32 bits -- added to the int64 sum
+         * (inthalfbandfiltereo.h:818-827, 858-867); the result `acc >> 11` is narrowed to the int32 it is stored in. */
+        int64_t wr = 0, wi = 0;
+        for (int i = 0; i < P; i++) {
+            const uint32_t a = (M - 2u * (uint32_t)i) & 63u;
+            const uint32_t b = (M - (uint32_t)(N - 2) + 2u * (uint32_t)i) & 63u;
+            wr += ((int64_t)s->re[a] + (int64_t)s->re[b]) * (int64_t)s->c[i];
+            wi += ((int64_t)s->im[a] + (int64_t)s->im[b]) * (int64_t)s->c[i];
+        }
+        const uint32_t mc = (M - (uint32_t)(N / 2 - 1)) & 63u;
+        wr += (int64_t)(int32_t)((uint32_t)s->re[mc] << (HB_SHIFT - 1));
+        wi += (int64_t)(int32_t)((uint32_t)s->im[mc] << (HB_SHIFT - 1));
+        *re = (int32_t)(uint32_t)(uint64_t)(wr >> (HB_SHIFT - 1));
+        *im = (int32_t)(uint32_t)(uint64_t)(wi >> (HB_SHIFT - 1));
+        return 1;
+    }
     uint32_t ar = 0, ai = 0;
     for (int i = 0; i < P; i++) {
         const uint32_t a = (M - 2u * (uint32_t)i) & 63u;
@@ -192,6 +211,44 @@ int32_t sdro_decimu_process(sdro_decim* d, const uint8_t* iq, int32_t n_u8, int1
     return n_out;
 }
 
+/* ------------------------------------------------------------------ 24-bit sample build (SDR_RX_SAMPLE_24BIT)
+ * Decimators<qint32, qint16, 24, InputBits> (decimators.h): same cascades, strides and stage modes, the six filters are
+ * IntHalfbandFilterEO<qint64,qint64,64>, shifts are decimation_shifts<24,InputBits> (:62-185), the Sample is {qint32, qint32}. */
+static void shifts24(int bits, int log2, int* pre, int* post)
+{
+    /* <24,16>: pre 8 - log2;  <24,12>: pre 12 - log2;  <24,8>: pre 16 - log2;  post 0 */
+    *pre = (bits == 16 ? 8 : bits == 12 ? 12 : 16) - log2; *post = 0;
+}
+
+sdro_decim* sdro_decim24_new(int log2, int fcpos, int bits)
+{
+    sdro_decim* d = sdro_decim_new(log2, fcpos, bits);
+    if (!d) return 0;
+    shifts24(bits, log2, &d->pre, &d->post);
+    for (int s = 0; s < log2; s++) d->st[s].wide = 1;
+    return d;
+}
+
+int32_t sdro_decim24_process(sdro_decim* d, const int16_t* iq, int32_t n_int16, int32_t* out)
+{
+    if (n_int16 < d->group) return 0;
+    const int32_t n_cplx = (n_int16 / d->group) * (d->group / 2);
+    int32_t n_out = 0;
+    for (int32_t i = 0; i < n_cplx; i++) {
+        int32_t re = (int32_t)((uint32_t)(int32_t)iq[2*i]   << d->pre);
+        int32_t im = (int32_t)((uint32_t)(int32_t)iq[2*i+1] << d->pre);
+        int s = 0;
+        for (; s < d->log2; s++)
+            if (!hb_push(&d->st[s], &re, &im)) break;
+        if (s == d->log2) {
+            out[2*n_out]   = re >> d->post;
+            out[2*n_out+1] = im >> d->post;
+            n_out++;
+        }
+    }
+    return n_out;
+}
+
 /* ------------------------------------------------------------------ DownChannelizer */
 static int contains(float ss, float se, float cs, float ce)
 {
@@ -283,6 +340,29 @@ int64_t sdro_chain_feed(sdro_chain* c, const int16_t* iq, int64_t n_cplx, int16_
     return n_out;
 }
 
+/* DownChannelizer of the 24-bit build: IntHalfbandFilterEO<qint64,qint64,48> stages (downchannelizer.h:78-81) on
+ * Sample{qint32, qint32}: int32 negation in the rotations, int32 store, the same final `/= (1 << n)` */
+sdro_chain* sdro_chain24_new(int32_t n_stages, const uint8_t* modes)
+{
+    sdro_chain* c = sdro_chain_new(n_stages, modes);
+    if (c) for (int i = 0; i < c->n; i++) { c->st[i].narrow = 0; c->st[i].wide = 1; }
+    return c;
+}
+
+int64_t sdro_chain24_feed(sdro_chain* c, const int32_t* iq, int64_t n_cplx, int32_t* out)
+{
+    if (c->n == 0) { memcpy(out, iq, (size_t)n_cplx * 8); return n_cplx; }
+    const int32_t div = 1 << c->n;
+    int64_t n_out = 0;
+    for (int64_t i = 0; i < n_cplx; i++) {
+        int32_t re = iq[2*i], im = iq[2*i+1];
+        int s = 0;
+        for (; s < c->n; s++)
+            if (!hb_push(&c->st[s], &re, &im)) break;
+        if (s == c->n) { out[2*n_out] = re / div; out[2*n_out+1] = im / div; n_out++; }
+    }
+    return n_out;
+}
 
 /* ------------------------------------------------------------------ DC offset correction of the device stream
  * DSPDeviceSourceEngine::iqCorrections(begin, end, imbalanceCorrection = false) (dspdevicesourceengine.cpp:175-181,255-259),

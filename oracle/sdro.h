@@ -101,6 +101,13 @@ void    sdro_iqimb_process(sdro_iqimb*, const int16_t* iq, int64_t n_cplx, int16
 /* ---- float half-band decimators: DecimatorsFI / FF / IF over IntHalfbandFilterEOF<64> (oracle/sdro_fdecim.c) ----
  * in_kind 0: float I/Q, 1: int16 I/Q (DecimatorsIF<qint16,input_bits>); out_kind 0: int16 Sample (FI), 1: float (FF, IF).
  * n_elems = the reference's nbIAndQ; returns #complex outputs (whole groups only, tail dropped). */
+/* 24-bit sample build (SDR_RX_SAMPLE_24BIT): Decimators<qint32,qint16,24,{8,12,16}> and the DownChannelizer stage chain on
+ * Sample{qint32,qint32}; objects are the same structs as the 16-bit flavour (free with sdro_decim_free / sdro_chain_free) */
+sdro_decim* sdro_decim24_new(int log2, int fcpos, int bits);
+int32_t sdro_decim24_process(sdro_decim*, const int16_t* iq, int32_t n_int16, int32_t* out_iq);
+sdro_chain* sdro_chain24_new(int32_t n_stages, const uint8_t* modes);
+int64_t sdro_chain24_feed(sdro_chain*, const int32_t* iq, int64_t n_cplx, int32_t* out_iq);
+
 /* audio-rate tails of the NFM / SSB demodulators (oracle/sdro_audio.c) */
 typedef struct sdro_nfmtail sdro_nfmtail;
 sdro_nfmtail* sdro_nfmtail_new(int32_t audio_rate, float fm_scaling, float squelch_level, int32_t squelch_gate, float volume, float af_bandwidth);

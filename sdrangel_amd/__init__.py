@@ -145,6 +145,21 @@ def lib() -> C.CDLL:
         "sdrx_iir_destroy": (C.c_int, [vp]),
         "sdrx_iir_reset": (C.c_int, [vp]),
         "sdrx_iir_feed": (C.c_int, [vp, vp, vp, vp]),
+        "sdrx_decim24_create": (C.c_int, [pp, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "sdrx_decim24_destroy": (C.c_int, [vp]),
+        "sdrx_decim24_reset": (C.c_int, [vp]),
+        "sdrx_decim24_process": (C.c_int, [vp, vp, i32, vp, C.POINTER(i32)]),
+        "sdrx_decim24_process_dev": (C.c_int, [vp, vp, i64, vp, C.POINTER(i64)]),
+        "sdrx_decim24_sync": (C.c_int, [vp]),
+        "sdrx_chan24_bank_feed_dev": (C.c_int, [vp, vp, i64]),
+        "sdrx_chan24_bank_out_dev": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(i64)]),
+        "sdrx_chan24_bank_sync": (C.c_int, [vp]),
+        "sdrx_chan24_bank_create": (C.c_int, [pp, C.c_int, i32, i32, vp, vp]),
+        "sdrx_chan24_bank_destroy": (C.c_int, [vp]),
+        "sdrx_chan24_bank_reset": (C.c_int, [vp]),
+        "sdrx_chan24_bank_info": (C.c_int, [vp, i32, C.POINTER(i32), vp, C.POINTER(i32), C.POINTER(i32)]),
+        "sdrx_chan24_bank_feed": (C.c_int, [vp, vp, i64]),
+        "sdrx_chan24_bank_read": (i64, [vp, i32, vp, i64]),
         "sdrx_firbank_create": (C.c_int, [pp, C.c_int, i32, vp]),
         "sdrx_firbank_destroy": (C.c_int, [vp]),
         "sdrx_firbank_feed": (C.c_int, [vp, vp, vp, vp]),
@@ -693,6 +708,93 @@ class IirBank:
         ns = (C.c_int64 * self.n_ch)(*[x.size for x in ins])
         _check(lib().sdrx_iir_feed(self._h, pi, ns, po), "sdrx_iir_feed")
         return [o[: x.size] for o, x in zip(outs, ins)]
+
+
+class Decimators24:
+    """Decimators<qint32, qint16, 24, InputBits> of the reference's 24-bit sample build (decimators.h, SDR_RX_SAMPLE_24BIT):
+    int16 I/Q in, {int32, int32} samples out; same call contract as Decimators.decimate()."""
+
+    def __init__(self, log2_decim: int, fcpos: int = FC_CEN, input_bits: int = 12, device: int = 0):
+        self._h = C.c_void_p()
+        _check(lib().sdrx_decim24_create(C.byref(self._h), device, log2_decim, fcpos, input_bits), "sdrx_decim24_create")
+        self.log2 = log2_decim
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sdrx_decim24_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def reset(self):
+        _check(lib().sdrx_decim24_reset(self._h), "sdrx_decim24_reset")
+
+    def decimate(self, buf) -> np.ndarray:
+        buf = np.ascontiguousarray(buf, dtype=np.int16)
+        out = np.empty(2 * ((buf.size // 2) >> self.log2) + 2, np.int32)
+        n = C.c_int32()
+        _check(lib().sdrx_decim24_process(self._h, buf.ctypes.data, buf.size, out.ctypes.data, C.byref(n)), "sdrx_decim24_process")
+        return out[: 2 * n.value]
+
+
+    def decimate_dev(self, d_iq: int, n_cplx: int, d_out: int) -> int:
+        """device pointers (e.g. torch tensor .data_ptr()); asynchronous, sync() waits; returns the samples produced"""
+        n = C.c_int64()
+        _check(lib().sdrx_decim24_process_dev(self._h, d_iq, n_cplx, d_out, C.byref(n)), "sdrx_decim24_process_dev")
+        return n.value
+
+    def sync(self):
+        _check(lib().sdrx_decim24_sync(self._h), "sdrx_decim24_sync")
+
+
+class ChannelizerBank24:
+    """N DownChannelizers (downchannelizer.cpp) of the 24-bit sample build on one {int32, int32} stream."""
+
+    def __init__(self, in_rate: int, req_rates, req_fcs, device: int = 0):
+        rr = np.ascontiguousarray(req_rates, dtype=np.int32); rf = np.ascontiguousarray(req_fcs, dtype=np.int32)
+        self.n_ch = rr.size
+        self._h = C.c_void_p()
+        _check(lib().sdrx_chan24_bank_create(C.byref(self._h), device, in_rate, self.n_ch, rr.ctypes.data, rf.ctypes.data), "sdrx_chan24_bank_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sdrx_chan24_bank_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def reset(self):
+        _check(lib().sdrx_chan24_bank_reset(self._h), "sdrx_chan24_bank_reset")
+
+    def info(self, ch: int):
+        n, r, f = C.c_int32(), C.c_int32(), C.c_int32()
+        modes = np.zeros(40, np.uint8)
+        _check(lib().sdrx_chan24_bank_info(self._h, ch, C.byref(n), modes.ctypes.data, C.byref(r), C.byref(f)), "sdrx_chan24_bank_info")
+        return modes[: n.value].copy(), r.value, f.value
+
+    def feed_dev(self, d_iq: int, n_cplx: int):
+        _check(lib().sdrx_chan24_bank_feed_dev(self._h, d_iq, n_cplx), "sdrx_chan24_bank_feed_dev")
+
+    def out_dev(self, ch: int):
+        p, n = C.c_void_p(), C.c_int64()
+        _check(lib().sdrx_chan24_bank_out_dev(self._h, ch, C.byref(p), C.byref(n)), "sdrx_chan24_bank_out_dev")
+        return p.value, n.value
+
+    def sync(self):
+        _check(lib().sdrx_chan24_bank_sync(self._h), "sdrx_chan24_bank_sync")
+
+    def feed(self, iq):
+        """iq: interleaved int32 I/Q; returns the per-channel outputs of this feed"""
+        iq = np.ascontiguousarray(iq, dtype=np.int32)
+        _check(lib().sdrx_chan24_bank_feed(self._h, iq.ctypes.data, iq.size // 2), "sdrx_chan24_bank_feed")
+        outs = []
+        for c in range(self.n_ch):
+            out = np.empty(iq.size + 2, np.int32)
+            n = lib().sdrx_chan24_bank_read(self._h, c, out.ctypes.data, out.size // 2)
+            if n < 0:
+                _check(int(n), "sdrx_chan24_bank_read")
+            outs.append(out[: 2 * n].copy())
+        return outs
 
 
 class IqImbalance:

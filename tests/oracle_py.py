@@ -34,6 +34,10 @@ def _sig(L):
     L.sdro_chain_new.restype = vp; L.sdro_chain_new.argtypes = [i32, vp]
     L.sdro_chain_free.argtypes = [vp]; L.sdro_chain_reset.argtypes = [vp]
     L.sdro_chain_feed.restype = i64; L.sdro_chain_feed.argtypes = [vp, vp, i64, vp]
+    L.sdro_decim24_new.restype = vp; L.sdro_decim24_new.argtypes = [C.c_int] * 3
+    L.sdro_decim24_process.restype = i32; L.sdro_decim24_process.argtypes = [vp, vp, i32, vp]
+    L.sdro_chain24_new.restype = vp; L.sdro_chain24_new.argtypes = [i32, vp]
+    L.sdro_chain24_feed.restype = i64; L.sdro_chain24_feed.argtypes = [vp, vp, i64, vp]
 
 
 def _sig_fdecim(L):
@@ -205,6 +209,44 @@ class Chain:
         iq = np.ascontiguousarray(iq, dtype=np.int16)
         out = np.empty(iq.size + 8, np.int16)
         n = lib().sdro_chain_feed(self.h, iq.ctypes.data, iq.size // 2, out.ctypes.data)
+        return out[: 2 * n].copy()
+
+
+class Decim24:
+    """Decimators<qint32, qint16, 24, bits> (the reference's SDR_RX_SAMPLE_24BIT build)"""
+
+    def __init__(self, log2, fcpos, bits):
+        self.h = lib().sdro_decim24_new(log2, fcpos, bits)
+        assert self.h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().sdro_decim_free(self.h); self.h = None
+
+    def process(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.int16)
+        out = np.empty(buf.size + 8, np.int32)
+        n = lib().sdro_decim24_process(self.h, buf.ctypes.data, buf.size, out.ctypes.data)
+        return out[: 2 * n].copy()
+
+
+class Chain24:
+    """one DownChannelizer stage chain of the 24-bit build: {int32, int32} in and out"""
+
+    def __init__(self, modes):
+        modes = np.ascontiguousarray(modes, dtype=np.uint8)
+        self.n = modes.size
+        self.h = lib().sdro_chain24_new(self.n, modes.ctypes.data)
+        assert self.h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().sdro_chain_free(self.h); self.h = None
+
+    def feed(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.int32)
+        out = np.empty(iq.size + 8, np.int32)
+        n = lib().sdro_chain24_feed(self.h, iq.ctypes.data, iq.size // 2, out.ctypes.data)
         return out[: 2 * n].copy()
 
 

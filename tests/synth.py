@@ -81,3 +81,31 @@ def fdecim_input(kind, n_cplx, seed):
 def fdecim_cuts(n_cplx):
     c = [0, 1000, 1001, n_cplx // 2 + 3, n_cplx]
     return list(zip(c[:-1], c[1:]))
+
+
+# ---- inputs of tests/golden/wide24_golden.* (the reference's SDR_RX_SAMPLE_24BIT build)
+W24_DEC_N = 12288 + 200
+W24_DEC_CUTS = [0, 0, 6, 2 * 2048 + 2, 2 * 5001, 2 * 9000 + 128, 2 * W24_DEC_N]
+W24_CH_N = 1 << 15
+W24_CH_CUTS = [0, 5, 4099, 4099, 20000, 20001, W24_CH_N]
+W24_CH_MODES = ([0], [1], [2], [1, 2, 0], [2, 2, 1, 0, 1], [0, 0, 0, 0, 0, 0, 0], [1, 0, 2, 1, 0, 2, 1, 0, 2, 1, 0, 2], [2, 1, 1, 0, 2, 0, 1, 2, 2, 0, 1, 1, 0])
+
+
+def w24_dec_inputs():
+    n = W24_DEC_N
+    w = np.empty(2 * n, np.int16); w[0::2] = -32768; w[1::2] = np.where(np.arange(n) % 3 == 0, 32767, -32768)
+    w[:4000] = noise_iq(2000, 14, 32767)
+    return {"b12": mix(n, 11, 2047, 900, 1), "b8": mix(n, 12, 127, 60, 1), "b16": mix(n, 13, 32767, 0), "wrap": w}
+
+
+def w24_chan_inputs():
+    """24-bit samples: a 16-bit noise word times 256 plus a second noise byte; `full` pins every 7th int32 to -2^23"""
+    hi = noise_iq(W24_CH_N, 41, 32767).astype(np.int32); lo = noise_iq(W24_CH_N, 42, 127).astype(np.int32)
+    full = hi * 256 + lo
+    full[::7] = -(1 << 23)
+    return {"n24": mix(W24_CH_N, 43, 32767, 9000, 3).astype(np.int32) * 64, "full": full}
+
+
+def noise24(n_cplx: int, seed: int) -> np.ndarray:
+    """full-range 24-bit I/Q as interleaved int32"""
+    return noise_iq(n_cplx, seed, 32767).astype(np.int32) * 256 + noise_iq(n_cplx, seed + 7919, 127).astype(np.int32)

@@ -273,3 +273,59 @@ def test_sample_sink_fifo_mirror_vs_the_real_class():
         env["LD_PRELOAD"] = pre
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fifo_vs_reference.py")], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "operations agree" in r.stdout and "sdriq vs reference FileRecord" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
+
+
+# ------------------------------------------------------------------ the 24-bit sample build (oracle/ref_shim24.cpp, -DSDR_RX_SAMPLE_24BIT)
+REF24 = os.path.join(ROOT, "oracle", "_ref", "libsdrref24.so")
+
+
+@pytest.fixture(scope="module")
+def ref24():
+    if not os.path.exists(REF24):
+        pytest.skip("oracle/_ref/libsdrref24.so not built (make -C oracle ref24)")
+    L = C.CDLL(REF24)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.ref24_decim_new.restype = vp; L.ref24_decim_new.argtypes = [C.c_int]
+    L.ref24_decim_free.argtypes = [vp]
+    L.ref24_decim_process.restype = C.c_int; L.ref24_decim_process.argtypes = [vp, C.c_int, C.c_int, vp, i32, vp]
+    L.ref24_chain_new.restype = vp; L.ref24_chain_new.argtypes = [C.c_int, vp]
+    L.ref24_chain_free.argtypes = [vp]
+    L.ref24_chain_feed.restype = i64; L.ref24_chain_feed.argtypes = [vp, vp, i64, vp]
+    assert L.ref24_sample_bytes() == 8
+    return L
+
+
+@pytest.mark.parametrize("bits", (8, 12, 16))
+def test_decimators24_random_splits(ref24, bits):
+    rng = np.random.default_rng(240 + bits)
+    for log2 in range(7):
+        for fc in range(3):
+            n = 20000
+            x = synth.mix(n, 2000 + bits + log2 * 3 + fc, int(rng.choice([127, 2047, 32767])), 500, 1)
+            if fc == 1:
+                x[::9] = -32768
+            cuts = sorted(set([0, 2 * n] + [2 * int(v) + int(rng.integers(0, 2)) * 2 for v in rng.integers(0, n, size=4)]))
+            h = ref24.ref24_decim_new(bits); o = orc.Decim24(log2, fc, bits)
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                seg = np.ascontiguousarray(x[a:b]); out = np.zeros(seg.size + 16, np.int32)
+                k = ref24.ref24_decim_process(h, log2, fc, seg.ctypes.data, seg.size, out.ctypes.data)
+                assert np.array_equal(o.process(seg), out[: 2 * k]), (bits, log2, fc, a, b)
+            ref24.ref24_decim_free(h)
+
+
+def test_chains24_random(ref24):
+    rng = np.random.default_rng(2424)
+    for trial in range(20):
+        ns = int(rng.integers(1, 14))
+        modes = rng.integers(0, 3, size=ns).astype(np.uint8)
+        n = 1 << 15
+        x = synth.noise24(n, 500 + trial) if trial % 2 else synth.noise24(n, 500 + trial) // 16
+        if trial % 4 == 0:
+            x[::5] = -(1 << 23)
+        h = ref24.ref24_chain_new(ns, modes.ctypes.data); o = orc.Chain24(modes)
+        cuts = sorted(set([0, n] + [int(v) for v in rng.integers(0, n, size=4)]))
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            seg = np.ascontiguousarray(x[2 * a: 2 * b]); out = np.zeros(seg.size + 16, np.int32)
+            k = ref24.ref24_chain_feed(h, seg.ctypes.data, b - a, out.ctypes.data)
+            assert np.array_equal(o.feed(seg), out[: 2 * k]), (trial, modes, a, b)
+        ref24.ref24_chain_free(h)
