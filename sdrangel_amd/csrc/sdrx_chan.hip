@@ -58,7 +58,15 @@ static int lds_budget_dw(size_t n_channels)
     if (e && atoi(e) >= 16 && atoi(e) <= 150) return atoi(e) * 1024 / 4 - 64;
     return n_channels >= 192 ? 64 * 1024 / 4 - 64 : LDS_BUDGET_DW_DEFAULT;
 }
-constexpr int LDS_HARD_DW = 150 * 1024 / 4;             // < the 159 KB of dynamic LDS the kernel may ask for
+constexpr int LDS_HARD_DW = 150 * 1024 / 4;
+// levels per pass: 6 = one warm-up chunk per segment.  Deeper passes (experiment, DESIGN 4.3: fewer node-stream bytes
+// for more LDS) need ceil(46 * (2^levels - 1) / 4096) warm-up chunks and as many more chunks of stream history.
+static int max_levels()
+{
+    const char* e = getenv("SDRX_CHAN_MAX_LEVELS");
+    if (e && atoi(e) >= 1 && atoi(e) <= TK_MAX_LEVELS) return atoi(e);
+    return TK_DEFAULT_LEVELS;
+}             // < the 159 KB of dynamic LDS the kernel may ask for
 
 struct HNode {
     int parent = -1, mode = 0, depth = 0;
@@ -82,6 +90,7 @@ struct Channel {
 struct Stream {
     int trie_node = 0, depth = 0, pass = 0, subtree = -1;
     uint32_t* hist[2] = { nullptr, nullptr };
+    long hist_len = TK_HIST;      // samples kept between feeds: (warm-up chunks of its subtree + 1) chunks
     int cur = 0;
     DevBuf mid;                   // new samples of a node stream (unused for the raw stream)
     int sink = -1;                // sink (in the producing pass) that fills `mid`
@@ -197,12 +206,15 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
         const int h = height(g->trie, root);
         if (h == 0) { g->streams[si].subtree = -1; continue; }
         int levels = 1, nn = 0;
-        while (levels < std::min(h, TK_MAX_LEVELS) && subtree_lds(g->trie, root, levels + 1, &nn) <= lds_budget_dw(g->chans.size())) levels++;
+        while (levels < std::min(h, max_levels()) && subtree_lds(g->trie, root, levels + 1, &nn) <= lds_budget_dw(g->chans.size())) levels++;
         int lds_need = subtree_lds(g->trie, root, levels, &nn);
         if (lds_need > LDS_HARD_DW) { set_error("channel tree does not fit LDS"); return SDRX_EINVAL; }
 
         TkSubtree st; memset(&st, 0, sizeof st);
         st.n_levels = levels;
+        st.warm = (int)((46L * ((1L << levels) - 1) + TK_CHUNK - 1) / TK_CHUNK);
+        if (st.warm < 1) st.warm = 1;
+        g->streams[si].hist_len = (long)(st.warm + 1) * TK_CHUNK;
         st.node_base = (int)g->nodes.size();
         st.array_base = (int)g->arrays.size();
         // window offsets are assigned per producer level inside region (level & 1); fixed up to absolute LDS offsets below
@@ -349,8 +361,8 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
     // device: histories + static tables
     for (auto& s : g->streams) {
         for (int i = 0; i < 2; i++) {
-            SDRX_HIP(hipMalloc(reinterpret_cast<void**>(&s.hist[i]), TK_HIST * 4));
-            SDRX_HIP(hipMemsetAsync(s.hist[i], 0, TK_HIST * 4, b->stream));
+            SDRX_HIP(hipMalloc(reinterpret_cast<void**>(&s.hist[i]), (size_t)s.hist_len * 4));
+            SDRX_HIP(hipMemsetAsync(s.hist[i], 0, (size_t)s.hist_len * 4, b->stream));
         }
     }
     const size_t b0 = g->subtrees.size() * sizeof(TkSubtree), b1 = g->nodes.size() * sizeof(TkNode), b2 = g->arrays.size() * sizeof(TkArray);
@@ -480,7 +492,8 @@ static int feed_group(sdrx_chan_bank* b, Group* g, const uint32_t* d_in, int64_t
         t.c_first = t.t_old / TK_CHUNK;
         t.c_last = t.t_new > t.t_old ? (t.t_new - 1) / TK_CHUNK : t.c_first - 1;
         t.cps = 1;
-        hh[si] = TkHistJob{ s.hist[s.cur], t.in, s.hist[s.cur ^ 1], t.t_new - t.t_old };
+        t.hist_len = s.hist_len;
+        hh[si] = TkHistJob{ s.hist[s.cur], t.in, s.hist[s.cur ^ 1], t.t_new - t.t_old, s.hist_len };
     }
     for (size_t k = 0; k < nk; k++) {
         const SinkInfo& si = g->sinks[k];
@@ -518,7 +531,6 @@ static int feed_group(sdrx_chan_bank* b, Group* g, const uint32_t* d_in, int64_t
     const TkStream* d_streams = reinterpret_cast<const TkStream*>(dp);
     const TkSink* d_sinks = reinterpret_cast<const TkSink*>(dp + o_sinks);
     const TkHistJob* d_hist = reinterpret_cast<const TkHistJob*>(dp + o_hist);
-    const size_t lds_bytes = (size_t)g->max_lds_dw * 4;
     rc = b->timer.begin(b->stream); if (rc) return rc;
     for (size_t p = 0; p < g->passes.size(); p++) {
         // the streams of one pass are contiguous in creation order; launch them as grid.y
@@ -528,6 +540,8 @@ static int feed_group(sdrx_chan_bank* b, Group* g, const uint32_t* d_in, int64_t
         for (int si : ps) max_segs = std::max(max_segs, segs[si]);
         if (max_segs == 0) continue;
         const int s0 = ps.front(), cnt = (int)ps.size();
+        size_t lds_bytes = 0;                              // per pass: a deep pass must not cost the shallow ones their occupancy
+        for (int si : ps) lds_bytes = std::max(lds_bytes, (size_t)g->subtrees[(size_t)g->streams[(size_t)si].subtree].lds_dwords * 4);
         hipLaunchKernelGGL(tree_kernel, dim3((unsigned)max_segs, (unsigned)cnt), dim3(TK_THREADS), lds_bytes, b->stream,
                            g->d_subtrees, g->d_nodes, g->d_arrays, d_streams + s0, d_sinks);
         SDRX_HIP(hipGetLastError());
@@ -537,7 +551,9 @@ static int feed_group(sdrx_chan_bank* b, Group* g, const uint32_t* d_in, int64_t
         }
     }
     rc = b->timer.end(b->stream); if (rc) return rc;
-    hipLaunchKernelGGL(tree_hist_kernel, dim3(TK_HIST / 256, (unsigned)ns), dim3(256), 0, b->stream, d_hist);
+    long max_hist = TK_HIST;
+    for (auto& s : g->streams) max_hist = std::max(max_hist, s.hist_len);
+    hipLaunchKernelGGL(tree_hist_kernel, dim3((unsigned)(max_hist / 256), (unsigned)ns), dim3(256), 0, b->stream, d_hist);
     SDRX_HIP(hipGetLastError());
     for (auto& s : g->streams) s.cur ^= 1;
     for (int c : g->chans) {

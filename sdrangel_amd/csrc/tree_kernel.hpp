@@ -5,10 +5,11 @@
 //
 // The N channels' stage strings form a trie; every distinct prefix (= node) is ONE order-48
 // half-band stage evaluated ONCE.  The host planner (sdrx_chan.hip) cuts the trie into passes of
-// at most 6 levels: a pass reads a stream (the raw input, or a node stream a previous pass wrote
-// to global memory), walks it in chunks of 4096 samples with all stage histories carried in LDS,
-// and writes channel outputs and/or deeper node streams.  One warm-up chunk (4096 >= 46*(2^6-1))
-// in front of every time segment makes the carried LDS state exact.
+// at most 6 levels by default (TK_MAX_LEVELS is the structural limit): a pass reads a stream (the raw
+// input, or a node stream a previous pass wrote to global memory), walks it in chunks of 4096 samples
+// with all stage histories carried in LDS, and writes channel outputs and/or deeper node streams.
+// `warm` warm-up chunks (warm * 4096 >= 46*(2^levels - 1): one chunk up to 6 levels) in front of every
+// time segment make the carried LDS state exact.
 //
 // Everything here is int16 by construction (Sample storage), so every stage runs on packed int16
 // polyphase arms with v_dot2c_i32_i16 (stage_pk16_r8).  The int16-wrapping negation of the
@@ -24,8 +25,9 @@ namespace sdrx {
 
 constexpr int TK_CHUNK = 4096;
 constexpr int TK_THREADS = 256;
-constexpr int TK_MAX_LEVELS = 6;
-constexpr int TK_HIST = 2 * TK_CHUNK;        // samples of stream history kept between feeds
+constexpr int TK_MAX_LEVELS = 10;
+constexpr int TK_DEFAULT_LEVELS = 6;         // what the planner uses unless told otherwise (one warm-up chunk)
+constexpr int TK_HIST = 2 * TK_CHUNK;        // samples of stream history kept between feeds: (warm + 1) chunks, this for warm = 1
 
 // One table entry = one half-band stage, or a FUSED lower/upper sibling pair: the lower- and the upper-half
 // child of a node rotate the odd arm identically (j^(n+1) = (-j)^(n+1) for odd n) and only differ in the sign
@@ -58,6 +60,7 @@ struct TkLevel {
 
 struct TkSubtree {
     int n_levels;
+    int warm;                   // warm-up chunks in front of a segment
     int n_nodes;                // all levels
     int node_base;              // first node (global index) -- levels index relative to the table
     int n_arrays, array_base;   // all arrays: [root arrays][level-1 arrays][level-2 arrays]...
@@ -77,12 +80,13 @@ struct TkSubtree {
 struct TkArray { int off, len, store, pad; };
 
 struct TkStream {               // per feed, per input stream of a pass
-    const uint32_t* hist;       // TK_HIST samples: absolute positions [t_old - TK_HIST, t_old)
+    const uint32_t* hist;       // hist_len samples: absolute positions [t_old - hist_len, t_old)
     const uint32_t* in;         // new samples: absolute positions [t_old, t_new)
     long t_old, t_new;
     long c_first, c_last;       // absolute chunk range to (re)compute
     int cps;                    // chunks per segment
     int subtree;
+    long hist_len;              // (warm + 1) * TK_CHUNK
 };
 
 struct TkSink {                 // where a node's outputs go in global memory
@@ -140,16 +144,16 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const long p = p0 + e;
-                    v[e] = p < sp.t_old ? sp.hist[p - (sp.t_old - TK_HIST)] : (p < sp.t_new ? sp.in[p - sp.t_old] : 0u);
+                    v[e] = p < sp.t_old ? sp.hist[p - (sp.t_old - sp.hist_len)] : (p < sp.t_new ? sp.in[p - sp.t_old] : 0u);
                 }
                 pre[j] = make_uint4(v[0], v[1], v[2], v[3]);
             }
         }
     };
-    fetch(first - 1);
+    fetch(first - st.warm);
     __syncthreads();
 
-    for (long chunk = first - 1; chunk <= last; ++chunk) {
+    for (long chunk = first - st.warm; chunk <= last; ++chunk) {
         // ---- stream samples -> root arms
 #pragma unroll
         for (int j = 0; j < LPT; j++) {
@@ -338,15 +342,15 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
     }
 }
 
-// new history = last TK_HIST samples of (old history ++ new samples); one block row per stream
-struct TkHistJob { const uint32_t* old_hist; const uint32_t* in; uint32_t* new_hist; long n_new; };
+// new history = last hist_len samples of (old history ++ new samples); one block row per stream
+struct TkHistJob { const uint32_t* old_hist; const uint32_t* in; uint32_t* new_hist; long n_new; long hist_len; };
 
 __global__ void tree_hist_kernel(const TkHistJob* __restrict__ jobs)
 {
     const TkHistJob jb = jobs[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= TK_HIST) return;
-    const long src = (long)i + jb.n_new - TK_HIST;
+    if (i >= jb.hist_len) return;
+    const long src = (long)i + jb.n_new - jb.hist_len;
     jb.new_hist[i] = src >= 0 ? jb.in[src] : jb.old_hist[i + jb.n_new];
 }
 

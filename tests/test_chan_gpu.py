@@ -178,3 +178,25 @@ def test_add_and_remove_channel_leave_the_others_alone():
     bank.reconfigure(1, 48000, fcs[1])                              # a removed index can be revived
     bank.feed(a)
     assert np.array_equal(bank.read(1), orc.Chain(ref[1][1]).feed(a))
+
+
+@pytest.mark.parametrize("levels,lds_kb", [(8, 80), (10, 150)])
+def test_deep_pass_plans_stay_exact(levels, lds_kb, monkeypatch):
+    """SDRX_CHAN_MAX_LEVELS / SDRX_CHAN_LDS_KB (the experiment of DESIGN 4.3: deeper first pass, fewer node-stream bytes):
+    more than six levels per pass need several warm-up chunks and a longer stream history -- same samples"""
+    monkeypatch.setenv("SDRX_CHAN_MAX_LEVELS", str(levels))
+    monkeypatch.setenv("SDRX_CHAN_LDS_KB", str(lds_kb))
+    rates, fcs = cfg3_channels(32)
+    n = 600_000
+    x = orc.synth_iq(n, seed=77, amp=32767, tone=None)
+    x[::7] = -32768
+    bank = sa.ChannelizerBank(FS, rates, fcs)
+    ref = oracle_bank(FS, rates, fcs)
+    cuts = [0, 5, 4099, 70001, 70001, 300000, 300001, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        seg = x[2 * a: 2 * b]
+        bank.feed(seg)
+        for c, (chain, *_r) in enumerate(ref):
+            got = bank.read(c)
+            assert np.array_equal(got, chain.feed(seg)), (levels, c, a, b)
+    bank.close()
