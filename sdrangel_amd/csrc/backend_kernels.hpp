@@ -538,7 +538,11 @@ __global__ void be_finish_kernel(BeChan* __restrict__ ch, const BeBufs* __restri
         } else {
             float2 m1; if (j == 0) { m1.x = s.m1r; m1.y = s.m1i; } else m1 = sample(j - 1);
             const float dr = m1.x * v.x - (-m1.y) * v.y, di = m1.x * v.y + (-m1.y) * v.x;    // conj(prev) * cur
-            b.real_out[j] = (float)(((double)atan2f(di, dr) / 3.14159265358979323846) * (double)s.fm_scaling);
+            // std::arg(complex<float>) = atan2f: evaluated in double and rounded once, i.e. the correctly rounded float
+            // (up to double rounding, ~2^-29 of the cases) -- glibc's atan2f is within 1-2 ulp of that, the device libm's
+            // float atan2f is not better, so this is the closest a different libm can get to the host's value
+            const float ang = (float)atan2((double)di, (double)dr);
+            b.real_out[j] = (float)(((double)ang / 3.14159265358979323846) * (double)s.fm_scaling);
         }
     }
 }
