@@ -110,6 +110,19 @@ int sdrx_decim_sync(sdrx_decim_t* h);
 int sdrx_decim_set_stream(sdrx_decim_t* h, void* hip_stream);
 /* #int16 consumed per loop iteration of the matching reference function (its `pos +=`) */
 int sdrx_decim_group_int16(int log2_decim, int fcpos);
+/* One reference Decimators object runs every decimateK_x on the SAME six half-band filters (m_decimator2 .. m_decimator64,
+ * decimators.h:326-333): a device thread that changes log2Decim or fcPos at run time continues on whatever each stage saw
+ * last.  A handle here is one variant; `sdrx_decim_stages_t` is the object's shared filter set.  On a change of variant:
+ *     sdrx_decim_save_stages(old_handle, stages);      stages 1..log2(old) := what old_handle's filters hold now
+ *     sdrx_decim_load_stages(new_handle, stages);      new_handle continues from them (its own history is forgotten)
+ * and the outputs equal the reference object's, bit for bit (include/sdrx/dsp.hpp does this inside sdrx::Decimators).
+ * Cost: a few milliseconds per change (a one-lane walk over 4096 samples on the device); nothing on the steady path. */
+typedef struct sdrx_decim_stages sdrx_decim_stages_t;
+int sdrx_decim_stages_create(sdrx_decim_stages_t** s, int device);
+int sdrx_decim_stages_destroy(sdrx_decim_stages_t* s);
+int sdrx_decim_save_stages(sdrx_decim_t* h, sdrx_decim_stages_t* s);
+int sdrx_decim_load_stages(sdrx_decim_t* h, const sdrx_decim_stages_t* s);
+
 /* checkpoint of the carried state (the last `sdrx_decim_state_bytes()` bytes of consumed input;
  * the six ring buffers of the reference are a pure function of it) */
 int64_t sdrx_decim_state_bytes(const sdrx_decim_t* h);

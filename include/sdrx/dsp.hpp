@@ -9,11 +9,13 @@
 //   SampleSinkFifo                (dsp/samplesinkfifo.h)   sdrx::SampleSinkFifo
 //   DecimatorsFI / FF / IF<T,B>   (dsp/decimatorsf*.h, decimatorsif.h)  sdrx::DecimatorsFI / DecimatorsFF / DecimatorsIF<T,B>
 //
-// Differences that are visible: (1) the reference keeps ONE set of six stage states per Decimators
-// object shared by all decimateK_* methods; here every (K, fcPos) pair owns its state (handle created
-// on first use), so switching K at run time starts from zero history instead of from the other
-// chain's leftovers; (2) DSP calls still return void -- a failing GPU call is logged to stderr and the
-// output iterator does not advance (the reference has no error path at all on these calls).
+// The reference keeps ONE set of six stage states per Decimators object, shared by all decimateK_* methods.  Here every
+// (K, fcPos) pair is a handle (created on first use) and the object carries a sdrx_decim_stages_t: when a call names another
+// variant than the previous one, the old handle's filters are saved into it and the new handle continues from them
+// (sdrx_decim_save_stages / sdrx_decim_load_stages), so a change of K or fcPos at run time gives the reference object's
+// samples, leftovers of the other cascade included.  (DecimatorsFI/FF/IF below still keep one state per variant.)
+// Visible difference: DSP calls still return void -- a failing GPU call is logged to stderr and the output iterator does
+// not advance (the reference has no error path at all on these calls).
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -47,8 +49,8 @@ template<typename StorageType, typename T, unsigned SdrBits, unsigned InputBits>
 class Decimators {
     static_assert(sizeof(T) == 2 && SdrBits == 16, "this build covers Decimators<qint32,qint16,16,{8,12,16}>");
 public:
-    explicit Decimators(int device = 0) : m_device(device) { for (auto& row : m_h) for (auto& h : row) h = nullptr; }
-    ~Decimators() { for (auto& row : m_h) for (auto& h : row) if (h) sdrx_decim_destroy(h); }
+    explicit Decimators(int device = 0) : m_device(device), m_stages(nullptr), m_last(nullptr) { for (auto& row : m_h) for (auto& h : row) h = nullptr; }
+    ~Decimators() { for (auto& row : m_h) for (auto& h : row) if (h) sdrx_decim_destroy(h); if (m_stages) sdrx_decim_stages_destroy(m_stages); }
     Decimators(const Decimators&) = delete;
     Decimators& operator=(const Decimators&) = delete;
 
@@ -68,6 +70,13 @@ private:
             std::fprintf(stderr, "sdrx::Decimators: %s\n", sdrx_last_error());
             h = nullptr; return;
         }
+        if (log2 > 0 && h != m_last) {                     // another cascade on the same six filters (decimators.h:326-333)
+            if (!m_stages && sdrx_decim_stages_create(&m_stages, m_device) != SDRX_OK) { std::fprintf(stderr, "sdrx::Decimators: %s\n", sdrx_last_error()); return; }
+            if ((m_last && sdrx_decim_save_stages(m_last, m_stages) != SDRX_OK) || sdrx_decim_load_stages(h, m_stages) != SDRX_OK) {
+                std::fprintf(stderr, "sdrx::Decimators: %s\n", sdrx_last_error()); return;
+            }
+            m_last = h;
+        }
         int32_t n = 0;
         // Sample is a packed {int16,int16}: the vector's storage is the output buffer
         if (sdrx_decim_process(h, reinterpret_cast<const int16_t*>(buf), len,
@@ -79,6 +88,8 @@ private:
     }
     int m_device;
     sdrx_decim_t* m_h[7][3];
+    sdrx_decim_stages_t* m_stages;
+    sdrx_decim_t* m_last;
 };
 
 // DecimatorsU<qint32, quint8, 16, 8, Shift> (dsp/decimatorsu.h:175-216), the RTL-SDR thread's member
@@ -87,8 +98,8 @@ template<typename StorageType, typename T, unsigned SdrBits, unsigned InputBits,
 class DecimatorsU {
     static_assert(sizeof(T) == 1 && SdrBits == 16 && InputBits == 8, "this build covers DecimatorsU<qint32,quint8,16,8,Shift>");
 public:
-    explicit DecimatorsU(int device = 0) : m_device(device) { for (auto& row : m_h) for (auto& h : row) h = nullptr; }
-    ~DecimatorsU() { for (auto& row : m_h) for (auto& h : row) if (h) sdrx_decim_destroy(h); }
+    explicit DecimatorsU(int device = 0) : m_device(device), m_stages(nullptr), m_last(nullptr) { for (auto& row : m_h) for (auto& h : row) h = nullptr; }
+    ~DecimatorsU() { for (auto& row : m_h) for (auto& h : row) if (h) sdrx_decim_destroy(h); if (m_stages) sdrx_decim_stages_destroy(m_stages); }
     DecimatorsU(const DecimatorsU&) = delete;
     DecimatorsU& operator=(const DecimatorsU&) = delete;
     void decimate1(SampleVector::iterator* it, const T* buf, int32_t len) { run(0, SDRX_FC_CEN, it, buf, len); }
@@ -105,6 +116,13 @@ private:
         if (!h && sdrx_decim_create_u8(&h, m_device, log2, fcpos, Shift) != SDRX_OK) {
             std::fprintf(stderr, "sdrx::DecimatorsU: %s\n", sdrx_last_error()); h = nullptr; return;
         }
+        if (log2 > 0 && h != m_last) {
+            if (!m_stages && sdrx_decim_stages_create(&m_stages, m_device) != SDRX_OK) { std::fprintf(stderr, "sdrx::DecimatorsU: %s\n", sdrx_last_error()); return; }
+            if ((m_last && sdrx_decim_save_stages(m_last, m_stages) != SDRX_OK) || sdrx_decim_load_stages(h, m_stages) != SDRX_OK) {
+                std::fprintf(stderr, "sdrx::DecimatorsU: %s\n", sdrx_last_error()); return;
+            }
+            m_last = h;
+        }
         int32_t n = 0;
         if (sdrx_decim_process_u8(h, reinterpret_cast<const uint8_t*>(buf), len, reinterpret_cast<int16_t*>(&**it), &n) != SDRX_OK) {
             std::fprintf(stderr, "sdrx::DecimatorsU: %s\n", sdrx_last_error()); return;
@@ -113,6 +131,8 @@ private:
     }
     int m_device;
     sdrx_decim_t* m_h[7][3];
+    sdrx_decim_stages_t* m_stages;
+    sdrx_decim_t* m_last;
 };
 
 // ---- float half-band decimators (dsp/decimatorsfi.h, decimatorsff.h, decimatorsif.h) over sdrx_fdecim_*.

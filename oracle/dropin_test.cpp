@@ -134,6 +134,36 @@ void producer_side(int device)
     PRODUCER(RefDec12, GpuDec12, qint16, decimate2_cen, -2048, 4096)
     PRODUCER(RefDec12, GpuDec12, qint16, decimate1, -2048, 4096)
     PRODUCER(RefDec16, GpuDec16, qint16, decimate4_inf, -32768, 65536)      // full-scale 16-bit source
+    {
+        // ONE object, the device thread changes log2Decim / fcPos while running (limesdrinputthread.cpp:103-135 switches on
+        // m_log2Decim and m_fcPos in every callback): all cascades share the object's six filters (decimators.h:326-333)
+        RefDec12 ref; GpuDec12 gpu(device);
+        int call = 0;
+        auto both = [&](SampleVector::iterator* itR, SampleVector::iterator* itG, const qint16* b, qint32 len) {
+            switch (call) {
+            case 0: ref.decimate64_cen(itR, b, len); gpu.decimate64_cen(itG, b, len); break;
+            case 1: ref.decimate8_inf(itR, b, len);  gpu.decimate8_inf(itG, b, len);  break;     // a short stay: 1000 samples
+            case 2: ref.decimate64_cen(itR, b, len); gpu.decimate64_cen(itG, b, len); break;     // back: stages 4-6 still hold call 0's tail
+            case 3: ref.decimate2_sup(itR, b, len);  gpu.decimate2_sup(itG, b, len);  break;
+            case 4: ref.decimate1(itR, b, len);      gpu.decimate1(itG, b, len);      break;     // touches no filter
+            case 5: ref.decimate32_sup(itR, b, len); gpu.decimate32_sup(itG, b, len); break;
+            default: ref.decimate16_cen(itR, b, len); gpu.decimate16_cen(itG, b, len); break;
+            }
+        };
+        const int lens[] = { 65536, 2000, 6000, 4096, 512, 30000, 65536, 65536 };
+        SampleVector refOut(400000), gpuOut(400000);
+        SampleVector::iterator itR = refOut.begin(), itG = gpuOut.begin();
+        std::vector<qint16> buf(65536);
+        for (int b = 0; b < 8; b++) {
+            call = b < 6 ? b : 6;
+            for (int i = 0; i < lens[b]; i++) buf[i] = (qint16)((int)(rng() % 4096) - 2048);
+            both(&itR, &itG, buf.data(), lens[b]);
+        }
+        bool same = (itR - refOut.begin()) == (itG - gpuOut.begin());
+        const long n = (long)(itR - refOut.begin());
+        for (long i = 0; same && i < n; i++) same = refOut[i].real() == gpuOut[i].real() && refOut[i].imag() == gpuOut[i].imag();
+        report("RefDec12: one object, K / fcPos changed at run time", same && n > 0, n);
+    }
 }
 
 // (3) the whole RX chain as the application runs it: device-thread blocks -> Decimators::decimate8_cen -> the reference's

@@ -163,6 +163,33 @@ sdro_decim* sdro_decim_new(int log2, int fcpos, int bits)
 
 void sdro_decim_free(sdro_decim* d) { free(d); }
 
+/* One Decimators object serves every decimateK_x with the SAME six filters (m_decimator2 .. m_decimator64,
+ * decimators.h:326-333): stage s of any cascade is member s.  Calling another variant on the object therefore starts from
+ * whatever each of its stages saw last (ring contents stay; the rotation pattern of myDecimateInf/Sup is positional inside a
+ * call, so it restarts).  Stages beyond the old cascade keep what they held before. */
+void sdro_decim_switch(sdro_decim* d, int log2, int fcpos)
+{
+    for (int s = 0; s < 6; s++) {
+        hb_stage* st = &d->st[s];
+        if (!st->order) { hb_init(st, 64, 0, 0); continue; }
+        int32_t re[64], im[64];
+        for (int k = 0; k < 64; k++) { re[k] = st->re[(st->n + (uint32_t)k) & 63u]; im[k] = st->im[(st->n + (uint32_t)k) & 63u]; }
+        memcpy(st->re, re, sizeof re); memcpy(st->im, im, sizeof im);
+        st->n = 0;                                  /* oldest first: the next store goes to slot 0, phase 0 */
+    }
+    d->log2 = log2; d->fcpos = fcpos;
+    shifts(d->bits, log2, &d->pre, &d->post);
+    d->group = sdro_decim_group_int16(log2, fcpos);
+    for (int s = 0; s < log2; s++) {
+        int mode = 0;
+        if (fcpos != SDRO_FC_CEN) {
+            const int first = fcpos == SDRO_FC_INF ? 1 : 2, other = 3 - first;
+            mode = s == 0 ? first : (log2 >= 3 && s == log2 - 1) ? 0 : other;
+        }
+        d->st[s].mode = mode;
+    }
+}
+
 int32_t sdro_decim_process(sdro_decim* d, const int16_t* iq, int32_t n_int16, int16_t* out)
 {
     if (n_int16 < d->group) return 0;

@@ -28,6 +28,8 @@ typedef struct sdro_decim sdro_decim;
 sdro_decim* sdro_decim_new(int log2_decim, int fcpos, int input_bits);
 void        sdro_decim_free(sdro_decim*);
 void        sdro_decim_reset(sdro_decim*);
+/* the next call runs decimate{2^log2}_{fcpos} on the SAME six stage states (one Decimators object, several variants) */
+void        sdro_decim_switch(sdro_decim*, int log2_decim, int fcpos);
 /* iq: interleaved int16 I,Q; n_int16 = number of int16 (the reference's `len`).  Whole groups
  * only, tail dropped (decimators.h:3492).  Returns #complex outputs written to out_iq. */
 int32_t     sdro_decim_process(sdro_decim*, const int16_t* iq, int32_t n_int16, int16_t* out_iq);

@@ -149,6 +149,10 @@ def lib() -> C.CDLL:
         "sdrx_decim24_destroy": (C.c_int, [vp]),
         "sdrx_decim24_reset": (C.c_int, [vp]),
         "sdrx_decim24_process": (C.c_int, [vp, vp, i32, vp, C.POINTER(i32)]),
+        "sdrx_decim_stages_create": (C.c_int, [pp, C.c_int]),
+        "sdrx_decim_stages_destroy": (C.c_int, [vp]),
+        "sdrx_decim_save_stages": (C.c_int, [vp, vp]),
+        "sdrx_decim_load_stages": (C.c_int, [vp, vp]),
         "sdrx_decim24_process_dev": (C.c_int, [vp, vp, i64, vp, C.POINTER(i64)]),
         "sdrx_decim24_sync": (C.c_int, [vp]),
         "sdrx_chan24_bank_feed_dev": (C.c_int, [vp, vp, i64]),
@@ -243,6 +247,14 @@ class Decimators:
     def sync(self):
         _check(lib().sdrx_decim_sync(self._h), "sdrx_decim_sync")
 
+    def save_stages(self, stages: "DecimStages"):
+        """stages 1..log2 of `stages` := what this variant's filters hold now"""
+        _check(lib().sdrx_decim_save_stages(self._h, stages._h), "sdrx_decim_save_stages")
+
+    def load_stages(self, stages: "DecimStages"):
+        """continue from the shared filter set of one reference Decimators object (decimators.h:326-333)"""
+        _check(lib().sdrx_decim_load_stages(self._h, stages._h), "sdrx_decim_load_stages")
+
     # ---- pinned double-buffered host path: the receive buffer IS a slot of the handle's pinned ring
     def ring_create(self, slot_elems: int, n_slots: int, flush_slots: int = 1):
         _check(lib().sdrx_decim_ring_create(self._h, slot_elems, n_slots, flush_slots), "sdrx_decim_ring_create")
@@ -310,6 +322,48 @@ def decimate_dev_batch(handles, d_in_ptrs, n_elems, d_out_ptrs) -> list:
     no = (C.c_int64 * n)()
     _check(lib().sdrx_decim_process_dev_batch(hs, n, ins, ns, outs, no), "sdrx_decim_process_dev_batch")
     return list(no)
+
+
+class DecimStages:
+    """The six IntHalfbandFilterEO states that all decimateK_x of ONE reference Decimators object share."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        _check(lib().sdrx_decim_stages_create(C.byref(self._h), device), "sdrx_decim_stages_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sdrx_decim_stages_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
+class DecimatorsObject:
+    """One reference Decimators / DecimatorsU object: any decimateK_x per call, all on the same six stage states
+    (what include/sdrx/dsp.hpp's sdrx::Decimators does in C++)."""
+
+    def __init__(self, input_bits: int = 12, device: int = 0, u8_shift=None):
+        self.bits, self.device, self.u8_shift = input_bits, device, u8_shift
+        self._variants, self._stages, self._last = {}, DecimStages(device), None
+
+    def decimate(self, log2: int, fcpos: int, buf) -> np.ndarray:
+        d = self._variants.get((log2, fcpos))
+        if d is None:
+            d = DecimatorsU(log2, fcpos, self.u8_shift, self.device) if self.u8_shift is not None else Decimators(log2, fcpos, self.bits, self.device)
+            self._variants[(log2, fcpos)] = d
+        if log2 > 0 and d is not self._last:
+            if self._last is not None:
+                self._last.save_stages(self._stages)
+            d.load_stages(self._stages)
+            self._last = d
+        return d.decimate(buf)
+
+    def close(self):
+        for d in self._variants.values():
+            d.close()
+        self._variants = {}
+        self._stages.close()
 
 
 class DecimatorsU(Decimators):

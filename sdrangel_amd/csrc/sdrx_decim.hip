@@ -43,6 +43,83 @@ __global__ void hist_update_kernel(const HistJobs jobs, int hist_dw)
     job.new_hist[i] = src >= 0 ? job.in[src] : job.old_hist[i + job.n_in_dw];
 }
 
+// ---- explicit stage states: the six IntHalfbandFilterEO members of ONE Decimators object (m_decimator2 .. m_decimator64,
+// decimators.h:326-333).  Every decimateK_x of the object runs its cascade on the same six filters, so after a change of
+// K / fcPos the new cascade starts from what each stage saw last.  The parallel kernels derive the filter state from the
+// last 4096 input samples of THEIR variant; this serial walk (one lane: a variant change is a rare event) is the bridge:
+// it turns an input history into the six rings (`zero_init`, no output) and it runs the first 4096 samples after a change
+// from explicit rings (in/out), after which the input history alone determines the state again (62 * 63 < 4096).
+// Ring layout: per stage 64 (re, im) int32 pairs, oldest first, as stored by storeSample32 (i.e. AFTER the rotation).
+constexpr int SG_STAGES = 6, SG_RING = 64, SG_STAGE_DW = SG_RING * 2, SG_DW = SG_STAGES * SG_STAGE_DW;
+
+struct SerialJob {
+    const void* in; long n_in; uint32_t* out; int32_t* rings;
+    int L, pre, post, u8, in_shift, zero_init;
+    int mode[SG_STAGES];
+};
+
+__global__ void decim_serial_kernel(const SerialJob jb)
+{
+    __shared__ int ring[SG_STAGES][2][SG_RING];
+    __shared__ unsigned cnt[SG_STAGES];
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int s = 0; s < jb.L; s++) {
+        for (int k = 0; k < SG_RING; k++) {
+            ring[s][0][k] = jb.zero_init ? 0 : jb.rings[s * SG_STAGE_DW + 2 * k];
+            ring[s][1][k] = jb.zero_init ? 0 : jb.rings[s * SG_STAGE_DW + 2 * k + 1];
+        }
+        cnt[s] = 0;                                         // next store -> slot 0 (the oldest), rotation phase 0
+    }
+    long k_out = 0;
+    for (long i = 0; i < jb.n_in; i++) {
+        int re, im;
+        if (jb.u8) {
+            const uint32_t v = static_cast<const uint16_t*>(jb.in)[i];
+            re = (int)((uint32_t)((int)(v & 0xffu) - jb.in_shift) << jb.pre); im = (int)((uint32_t)((int)(v >> 8) - jb.in_shift) << jb.pre);
+        } else {
+            const uint32_t v = static_cast<const uint32_t*>(jb.in)[i];
+            re = (int)((uint32_t)(int)(int16_t)(v & 0xffffu) << jb.pre); im = (int)((uint32_t)(int)(int16_t)(v >> 16) << jb.pre);
+        }
+        int s = 0;
+        for (; s < jb.L; s++) {
+            const unsigned n = cnt[s];
+            int xr = re, xi = im;
+            const int mode = jb.mode[s];
+            if (mode) {                                     // inf: j^(n+1), sup: (-j)^(n+1)  (inthalfbandfiltereo.h:626-692)
+                const unsigned ph = n & 3u;
+                const int nr = (int)(0u - (uint32_t)re), ni = (int)(0u - (uint32_t)im);
+                if (ph == 1) { xr = nr; xi = ni; }
+                else if (ph != 3) {
+                    if ((ph == 0) == (mode == 1)) { xr = ni; xi = re; }        // inf ph 0 / sup ph 2: (-y, x)
+                    else { xr = im; xi = nr; }                                 // inf ph 2 / sup ph 0: (y, -x)
+                }
+            }
+            const unsigned M = n & 63u;
+            ring[s][0][M] = xr; ring[s][1][M] = xi;
+            cnt[s] = n + 1;
+            if (!(n & 1u)) break;
+            uint32_t ar = 0, ai = 0;
+            for (int t = 0; t < 16; t++) {
+                const unsigned a = (M - 2u * (unsigned)t) & 63u, b = (M - 62u + 2u * (unsigned)t) & 63u;
+                const uint32_t c = (uint32_t)hb_c<64>(t);
+                ar += ((uint32_t)ring[s][0][a] + (uint32_t)ring[s][0][b]) * c;
+                ai += ((uint32_t)ring[s][1][a] + (uint32_t)ring[s][1][b]) * c;
+            }
+            const unsigned mc = (M - 31u) & 63u;
+            ar += (uint32_t)ring[s][0][mc] << (HB_SHIFT - 1);
+            ai += (uint32_t)ring[s][1][mc] << (HB_SHIFT - 1);
+            re = (int)ar >> (HB_SHIFT - 1); im = (int)ai >> (HB_SHIFT - 1);
+        }
+        if (s == jb.L && jb.out) jb.out[k_out++] = pack_iq(re >> jb.post, im >> jb.post);
+    }
+    for (int s = 0; s < jb.L; s++)
+        for (int k = 0; k < SG_RING; k++) {
+            const unsigned src = (cnt[s] + (unsigned)k) & 63u;               // cnt & 63 = the oldest entry
+            jb.rings[s * SG_STAGE_DW + 2 * k] = ring[s][0][src];
+            jb.rings[s * SG_STAGE_DW + 2 * k + 1] = ring[s][1][src];
+        }
+}
+
 typedef void (*chain_fn)(const DecimJobs, int, int, int);
 typedef void (*fast_fn)(const DecimJobs, int, int, int);
 
@@ -112,6 +189,10 @@ struct sdrx_decim {
     uint32_t* d_hist[2] = { nullptr, nullptr };
     int cur = 0;
     DevBuf d_in, d_out, d_flags;
+    // after sdrx_decim_load_stages: explicit rings, current while `since_load` < DC_CHUNK samples have been processed
+    int32_t* d_rings = nullptr;
+    bool rings_live = false;
+    long since_load = 0;
     int path = 0;                 // 0 auto (FAST + flagged EXACT), 1 exact only, 2 fast only (debug: no fallback)
     ChainEntry k{ nullptr, nullptr, "", "", 0, 0 };
     char last_name[96] = "";
@@ -155,11 +236,70 @@ static int choose_cps(long n_chunks, int slots)
     return (int)best;
 }
 
+static void stage_modes(int log2, int fcpos, int* mode)
+{
+    // decimateK_inf: Inf, Sup, ..., Sup, Cen ; _sup: Sup, Inf, ..., Inf, Cen ; K = 2: single ; K = 4: pair (decimators.h:463-2584)
+    for (int s = 0; s < SG_STAGES; s++) {
+        int m = 0;
+        if (s < log2 && fcpos != SDRX_FC_CEN) {
+            const int first = fcpos == SDRX_FC_INF ? 1 : 2, other = 3 - first;
+            m = s == 0 ? first : (log2 >= 3 && s == log2 - 1) ? 0 : other;
+        }
+        mode[s] = m;
+    }
+}
+
+static int launch_serial(sdrx_decim* h, hipStream_t stream, const void* d_in, long n, uint32_t* d_out, int32_t* d_rings, bool zero_init)
+{
+    SerialJob jb;
+    jb.in = d_in; jb.n_in = n; jb.out = d_out; jb.rings = d_rings;
+    jb.L = h->log2; jb.pre = h->pre; jb.post = h->post; jb.u8 = h->u8 ? 1 : 0; jb.in_shift = h->in_shift; jb.zero_init = zero_init ? 1 : 0;
+    stage_modes(h->log2, h->fcpos, jb.mode);
+    hipLaunchKernelGGL(decim_serial_kernel, dim3(1), dim3(64), 0, stream, jb);
+    SDRX_HIP(hipGetLastError());
+    return SDRX_OK;
+}
+
+// A handle that was given explicit stage states runs its first DC_CHUNK samples through the serial walk (outputs + updated
+// rings + its input history), then the parallel kernels take over.  Returns how many samples were consumed here.
+static int run_transition(sdrx_decim* x, hipStream_t stream, const void* d_iq, long n_cplx, int16_t* d_out, long* consumed)
+{
+    *consumed = 0;
+    if (!x->rings_live || n_cplx <= 0 || x->log2 == 0) return SDRX_OK;
+    long left = DC_CHUNK - x->since_load;
+    left = (left + 127) / 128 * 128;                       // keeps the rest of the call on whole groups and 16-byte aligned
+    const long m = n_cplx < left ? n_cplx : left;
+    int rc = launch_serial(x, stream, d_iq, m, reinterpret_cast<uint32_t*>(d_out), x->d_rings, false); if (rc) return rc;
+    const int hist_dw = DC_CHUNK * x->bps / 4;
+    HistJobs hj;
+    std::memset(&hj, 0, sizeof hj);
+    hj.j[0].old_hist = x->d_hist[x->cur]; hj.j[0].in = static_cast<const uint32_t*>(d_iq);
+    hj.j[0].new_hist = x->d_hist[x->cur ^ 1]; hj.j[0].n_in_dw = m * x->bps / 4;
+    hipLaunchKernelGGL(hist_update_kernel, dim3((unsigned)((hist_dw + 255) / 256), 1u), dim3(256), 0, stream, hj, hist_dw);
+    SDRX_HIP(hipGetLastError());
+    x->cur ^= 1;
+    x->since_load += m;
+    if (x->since_load >= DC_CHUNK) x->rings_live = false;
+    *consumed = m;
+    return SDRX_OK;
+}
+
 // One launch (per kernel) for n <= DJ_MAX streams of one configuration: hs[i] consumes n_cplx[i] whole-group samples
 // at d_iq[i] into d_out[i].  Everything is queued on hs[0]'s stream; timing and last_launch are kept on hs[0].
-static int launch_batch(sdrx_decim* const* hs, int n, const void* const* d_iq, const long* n_cplx, int16_t* const* d_out)
+static int launch_batch(sdrx_decim* const* hs, int n, const void* const* d_iq_in, const long* n_cplx_in, int16_t* const* d_out_in)
 {
     sdrx_decim* h = hs[0];
+    const void* d_iq[DJ_MAX]; long n_cplx[DJ_MAX]; int16_t* d_out[DJ_MAX];
+    for (int i = 0; i < n; i++) {
+        d_iq[i] = d_iq_in[i]; n_cplx[i] = n_cplx_in[i]; d_out[i] = d_out_in[i];
+        long used = 0;
+        int rc = run_transition(hs[i], h->stream, d_iq[i], n_cplx[i], d_out[i], &used); if (rc) return rc;
+        if (used) {
+            d_iq[i] = static_cast<const char*>(d_iq[i]) + used * hs[i]->bps;
+            d_out[i] += 2 * (used >> hs[i]->log2);
+            n_cplx[i] -= used;
+        }
+    }
     long total = 0, longest = 0;
     for (int i = 0; i < n; i++) { total += n_cplx[i]; if (n_cplx[i] > longest) longest = n_cplx[i]; }
     if (total <= 0) return SDRX_OK;
@@ -451,6 +591,7 @@ int sdrx_decim_destroy(sdrx_decim_t* h)
     (void)hipSetDevice(h->device);
     if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); }
     for (int i = 0; i < 2; i++) if (h->d_hist[i]) (void)hipFree(h->d_hist[i]);
+    if (h->d_rings) (void)hipFree(h->d_rings);
     h->d_in.release(); h->d_out.release(); h->d_flags.release(); h->timer.release();
     ring_free(h);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -464,6 +605,7 @@ int sdrx_decim_reset(sdrx_decim_t* h)
     SDRX_HIP(hipSetDevice(h->device));
     // a zero SAMPLE: all-zero bytes for int16 input, the byte `in_shift` for the unsigned 8-bit flavour
     SDRX_HIP(hipMemsetAsync(h->d_hist[h->cur], h->u8 ? h->in_shift : 0, (size_t)DC_CHUNK * h->bps, h->stream));
+    h->rings_live = false; h->since_load = 0;
     return SDRX_OK;
 }
 
@@ -603,6 +745,7 @@ int64_t sdrx_decim_state_bytes(const sdrx_decim_t* h) { return (int64_t)DC_CHUNK
 int sdrx_decim_get_state(sdrx_decim_t* h, void* host_buf)
 {
     if (!h || !host_buf) return SDRX_EINVAL;
+    if (h->rings_live) { set_error("sdrx_decim_get_state: the handle still runs on loaded stage states (first 4096 samples after sdrx_decim_load_stages); save those with sdrx_decim_save_stages"); return SDRX_ESTATE; }
     SDRX_HIP(hipSetDevice(h->device));
     SDRX_HIP(hipMemcpyAsync(host_buf, h->d_hist[h->cur], (size_t)DC_CHUNK * h->bps, hipMemcpyDeviceToHost, h->stream));
     SDRX_HIP(hipStreamSynchronize(h->stream));
@@ -615,6 +758,7 @@ int sdrx_decim_set_state(sdrx_decim_t* h, const void* host_buf)
     SDRX_HIP(hipSetDevice(h->device));
     SDRX_HIP(hipMemcpyAsync(h->d_hist[h->cur], host_buf, (size_t)DC_CHUNK * h->bps, hipMemcpyHostToDevice, h->stream));
     SDRX_HIP(hipStreamSynchronize(h->stream));
+    h->rings_live = false;
     return SDRX_OK;
 }
 
@@ -643,6 +787,66 @@ int sdrx_decim_last_launch(const sdrx_decim_t* h, char* kernel_name, int name_ca
     if (grid) *grid = h->last_grid;
     if (block) *block = h->last_block;
     if (lds_bytes) *lds_bytes = h->last_lds;
+    return SDRX_OK;
+}
+
+} // extern "C"
+
+/* ---- one Decimators object, several decimateK_x: the shared six stage states ------------------------------------- */
+struct sdrx_decim_stages { int device = 0; int32_t* d_rings = nullptr; };
+
+extern "C" {
+
+int sdrx_decim_stages_create(sdrx_decim_stages_t** out, int device)
+{
+    if (!out) { set_error("sdrx_decim_stages_create: null out"); return SDRX_EINVAL; }
+    *out = nullptr;
+    int rc = check_device(device); if (rc) return rc;
+    SDRX_HIP(hipSetDevice(device));
+    sdrx_decim_stages* s = new (std::nothrow) sdrx_decim_stages;
+    if (!s) return SDRX_ENOMEM;
+    s->device = device;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_rings), SG_DW * 4);
+    if (e == hipSuccess) e = hipMemset(s->d_rings, 0, SG_DW * 4);          // freshly constructed filters: all-zero rings
+    if (e != hipSuccess) { if (s->d_rings) (void)hipFree(s->d_rings); delete s; return hip_fail(e, "sdrx_decim_stages_create", __FILE__, __LINE__); }
+    *out = s;
+    return SDRX_OK;
+}
+
+int sdrx_decim_stages_destroy(sdrx_decim_stages_t* s)
+{
+    if (!s) return SDRX_OK;
+    (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();
+    if (s->d_rings) (void)hipFree(s->d_rings);
+    delete s;
+    return SDRX_OK;
+}
+
+int sdrx_decim_save_stages(sdrx_decim_t* h, sdrx_decim_stages_t* s)
+{
+    if (!h || !s || h->device != s->device) { set_error("sdrx_decim_save_stages: bad argument (handle and stage set must live on one device)"); return SDRX_EINVAL; }
+    SDRX_HIP(hipSetDevice(h->device));
+    if (h->log2 == 0) return SDRX_OK;                                       // decimate1 touches no filter
+    if (h->rings_live) {
+        SDRX_HIP(hipMemcpyAsync(s->d_rings, h->d_rings, (size_t)h->log2 * SG_STAGE_DW * 4, hipMemcpyDeviceToDevice, h->stream));
+    } else {
+        // steady state: the rings are a function of the last DC_CHUNK input samples (zero state in front of them is exact)
+        int rc = launch_serial(h, h->stream, h->d_hist[h->cur], DC_CHUNK, nullptr, s->d_rings, true); if (rc) return rc;
+    }
+    SDRX_HIP(hipStreamSynchronize(h->stream));
+    return SDRX_OK;
+}
+
+int sdrx_decim_load_stages(sdrx_decim_t* h, const sdrx_decim_stages_t* s)
+{
+    if (!h || !s || h->device != s->device) { set_error("sdrx_decim_load_stages: bad argument (handle and stage set must live on one device)"); return SDRX_EINVAL; }
+    SDRX_HIP(hipSetDevice(h->device));
+    if (h->log2 == 0) return SDRX_OK;
+    SDRX_HIP(hipStreamSynchronize(h->stream));
+    if (!h->d_rings) SDRX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_rings), SG_DW * 4));
+    SDRX_HIP(hipMemcpyAsync(h->d_rings, s->d_rings, SG_DW * 4, hipMemcpyDeviceToDevice, h->stream));
+    h->rings_live = true; h->since_load = 0;
     return SDRX_OK;
 }
 

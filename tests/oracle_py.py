@@ -27,6 +27,7 @@ def _sig(L):
     L.sdro_decim_new.restype = vp; L.sdro_decim_new.argtypes = [C.c_int] * 3
     L.sdro_decim_free.argtypes = [vp]; L.sdro_decim_reset.argtypes = [vp]
     L.sdro_decim_process.restype = i32; L.sdro_decim_process.argtypes = [vp, vp, i32, vp]
+    L.sdro_decim_switch.argtypes = [vp, C.c_int, C.c_int]
     L.sdro_decimu_new.restype = vp; L.sdro_decimu_new.argtypes = [C.c_int] * 3
     L.sdro_decimu_process.restype = i32; L.sdro_decimu_process.argtypes = [vp, vp, i32, vp]
     L.sdro_decim_group_int16.restype = i32; L.sdro_decim_group_int16.argtypes = [C.c_int] * 2

@@ -44,6 +44,29 @@ def test_decimators_random_splits(ref, bits):
             ref.ref_decim_free(h)
 
 
+def test_decimators_variant_switch(ref):
+    """ONE reference Decimators object called with changing (K, fcPos): all cascades share its six filters
+    (decimators.h:326-333).  The oracle's sdro_decim_switch models that; the GPU path is tested against the oracle."""
+    orc.lib().sdro_decim_switch.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    rng = np.random.default_rng(3)
+    for bits in (8, 12, 16):
+        for trial in range(25):
+            h = ref.ref_decim_new(bits); o = None; pos = 0
+            x = synth.mix(60000, 900 + trial, int(rng.choice([127, 2047, 32767])), 500, 1)
+            for seg in range(6):
+                log2, fc = int(rng.integers(0, 7)), int(rng.integers(0, 3))
+                n = int(rng.choice([8, 64, 200, 1000, 5000, 9000])) * 2
+                buf = np.ascontiguousarray(x[pos: pos + n]); pos += n
+                if o is None:
+                    o = orc.Decim(log2, fc, bits)
+                else:
+                    orc.lib().sdro_decim_switch(o.h, log2, fc); o.log2 = log2
+                out = np.zeros(buf.size + 16, np.int16)
+                k = ref.ref_decim_process(h, log2, fc, buf.ctypes.data, buf.size, out.ctypes.data)
+                assert np.array_equal(o.process(buf), out[: 2 * k]), (bits, trial, seg, log2, fc, n)
+            ref.ref_decim_free(h)
+
+
 def test_chains_random(ref):
     rng = np.random.default_rng(77)
     for trial in range(25):
