@@ -69,22 +69,23 @@ __device__ __forceinline__ void stage_pk16(const uint32_t* __restrict__ oI, cons
 
     static_for<0, R>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
-        int aI = 0, aQ = 0;
+        constexpr int dd = (r + 1) >> 1, hf = (r + 1) & 1;
+        // the accumulator starts as the centre tap (one SDWA shift) instead of 0 + a seventeenth dot2
+        int aI, aQ;
+        if constexpr (MODE == MODE_CEN) {
+            aI = centre_shl<hf>(vI[dd]); aQ = centre_shl<hf>(vQ[dd]);
+        } else {
+            // centre sample: inf: k odd -> (-im, re), k even -> (im, -re); sup: negated
+            constexpr bool neg_first = ((r & 1) == 1) == (MODE == MODE_INF);
+            const int cq = centre_shl<hf>(vQ[dd]), ci = centre_shl<hf>(vI[dd]);
+            aI = neg_first ? (int)(0u - (uint32_t)cq) : cq;
+            aQ = neg_first ? ci : (int)(0u - (uint32_t)ci);
+        }
         static_for<0, NW>([&](auto dc) {
             constexpr int d = decltype(dc)::value;
             constexpr uint32_t cf = pk_coef<ORDER, MODE>(r, d);
             if constexpr (cf != 0) { aI = dot2(wI[d], cf, aI); aQ = dot2(wQ[d], cf, aQ); }
         });
-        constexpr int dd = (r + 1) >> 1, hf = (r + 1) & 1;
-        constexpr uint32_t cp = hf ? pk16(0, 2048) : pk16(2048, 0);
-        constexpr uint32_t cn = hf ? pk16(0, -2048) : pk16(-2048, 0);
-        if constexpr (MODE == MODE_CEN) {
-            aI = dot2(vI[dd], cp, aI); aQ = dot2(vQ[dd], cp, aQ);
-        } else {
-            constexpr bool neg_first = ((r & 1) == 1) == (MODE == MODE_INF);
-            aI = dot2(vQ[dd], neg_first ? cn : cp, aI);
-            aQ = dot2(vI[dd], neg_first ? cp : cn, aQ);
-        }
         yI[r] = (int)((uint32_t)aI << SHL) >> (HB_SHIFT - 1);
         yQ[r] = (int)((uint32_t)aQ << SHL) >> (HB_SHIFT - 1);
     });
@@ -116,6 +117,17 @@ __device__ __forceinline__ void put_pk16(uint32_t* __restrict__ oI, uint32_t* __
 // coefficient pairs, partial sums combined over the SPLIT neighbouring lanes.  Every lane of a
 // (p, component) group ends up holding the finished outputs.
 // ---------------------------------------------------------------------------------------------
+// acc + d * c as ONE v_mad_i32_i24 (4 cycles).  Left to itself the compiler turns the chain into v_mul_i32_i24 plus one
+// v_add3_u32 per two products (4 + 2 cycles per tap pair).  KS: the coefficient is a compile-time constant -> SGPR operand.
+template<bool KS>
+__device__ __forceinline__ int mad24(int acc, int d, int c)
+{
+    int r;
+    if constexpr (KS) asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(d), "s"(c), "v"(acc));
+    else asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(d), "v"(c), "v"(acc));
+    return r;
+}
+
 template<int MODE, int SPLIT, bool M24>
 __device__ __forceinline__ void stage_i32_split(const int* __restrict__ oI, const int* __restrict__ oQ,
                                                 const int* __restrict__ eI, const int* __restrict__ eQ,
@@ -142,11 +154,11 @@ __device__ __forceinline__ void stage_i32_split(const int* __restrict__ oI, cons
             else if constexpr (SPLIT == 2) cf = h ? hb_c<64>(PP + ii) : hb_c<64>(ii);
             else cf = h == 0 ? hb_c<64>(ii) : h == 1 ? hb_c<64>(PP + ii) : h == 2 ? hb_c<64>(2 * PP + ii) : hb_c<64>(3 * PP + ii);
             if constexpr (MODE == MODE_CEN) {
-                acc[r] = mac<M24>(acc[r], (int)((uint32_t)av + (uint32_t)bv), cf);
+                acc[r] = M24 ? mad24<SPLIT == 1>(acc[r], (int)((uint32_t)av + (uint32_t)bv), cf) : mac<false>(acc[r], (int)((uint32_t)av + (uint32_t)bv), cf);
             } else {
                 // s(m) = (-1)^(m+1), m = k - i, k = 2p + r, i = h*PP + ii with PP even: parity of r - ii
                 constexpr int sg = (((r - ii) & 1) == 0) ? -1 : 1;
-                acc[r] = mac<M24>(acc[r], (int)((uint32_t)av - (uint32_t)bv), sg * cf);
+                acc[r] = M24 ? mad24<SPLIT == 1>(acc[r], (int)((uint32_t)av - (uint32_t)bv), sg * cf) : mac<false>(acc[r], (int)((uint32_t)av - (uint32_t)bv), sg * cf);
             }
         });
     });

@@ -68,6 +68,20 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t coef, int acc)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, coef), acc, false);
 }
 
+// sext(int16 half of v) << 11 in ONE full-rate instruction (SDWA operand select + sign extension): the centre tap
+// `x << (hbShift - 1)` of a stage whose even arm is packed int16.  Starting the accumulator with it replaces the
+// `v_mov 0` + `v_dot2c (2048, 0)` pair that a dot2-only chain needs (v_dot2c accumulates in place).
+template<int HALF>
+__device__ __forceinline__ int centre_shl(uint32_t v)
+{
+    int r;
+    if constexpr (HALF)
+        asm("v_lshlrev_b32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "s"(HB_SHIFT - 1), "v"(v));
+    else
+        asm("v_lshlrev_b32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "s"(HB_SHIFT - 1), "v"(v));
+    return r;
+}
+
 __host__ __device__ constexpr uint32_t pk16(int lo, int hi)
 {
     return (uint32_t)(uint16_t)(int16_t)lo | ((uint32_t)(uint16_t)(int16_t)hi << 16);

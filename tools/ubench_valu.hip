@@ -40,6 +40,18 @@ __global__ __launch_bounds__(256) void k(const int* __restrict__ in, int* __rest
                 else if (KIND == 17) asm volatile("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
                 else if (KIND == 18) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
                 else if (KIND == 19) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
+                else if (KIND == 21) asm volatile("v_lshlrev_b32_sdwa %0, %1, sext(%0) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "+v"(a[i]) : "s"(11));
+                else if (KIND == 22) asm volatile("v_pack_b32_f16 %0, %0, %1" : "+v"(a[i]) : "v"(x));
+                else if (KIND == 23) asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0" : "+v"(a[i]) : "v"(x));
+                else if (KIND == 24) asm volatile("v_ashrrev_i32_sdwa %0, %1, %0 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(a[i]) : "s"(3));
+                else if (KIND == 25) asm volatile("v_add_u32_sdwa %0, %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "+v"(a[i]) : "v"(x));
+                else if (KIND == 26) asm volatile("v_lshlrev_b32 %0, 11, %0" : "+v"(a[i]));
+                else if (KIND == 27) asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(a[i]) : "v"(x));
+                else if (KIND == 28) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(x));
+                else if (KIND == 29) asm volatile("v_cvt_pk_i16_i32 %0, %0, %1" : "+v"(a[i]) : "v"(x));
+                else if (KIND == 30) asm volatile("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "s"(1300));
+                else if (KIND == 31) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a[i]) : "v"(x), "v"(y));
+                else if (KIND == 32) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(x), "v"(y));
                 else if (KIND == 20) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(*(long long*)&a[i & 6]) : "v"(*(long long*)&a[(i+2)&6]), "v"(*(long long*)&a[(i+4)&6]));
             }
         }
@@ -96,5 +108,17 @@ int main()
     run<18>("v_dot2_f32_f16", din, dout, cus, g);
     run<19>("v_fma_f32", din, dout, cus, g);
     run<20>("v_pk_fma_f32", din, dout, cus, g);
+    run<21>("v_lshlrev_b32_sdwa", din, dout, cus, g);
+    run<26>("v_lshlrev_b32", din, dout, cus, g);
+    run<22>("v_pack_b32_f16", din, dout, cus, g);
+    run<23>("v_mov_b32_sdwa", din, dout, cus, g);
+    run<24>("v_ashrrev_sdwa", din, dout, cus, g);
+    run<25>("v_add_u32_sdwa", din, dout, cus, g);
+    run<27>("v_mul_i32_i24", din, dout, cus, g);
+    run<28>("v_and_b32", din, dout, cus, g);
+    run<29>("v_cvt_pk_i16_i32", din, dout, cus, g);
+    run<30>("v_mad_i32_i24 sgpr", din, dout, cus, g);
+    run<31>("v_bfi_b32", din, dout, cus, g);
+    run<32>("v_and_or_b32", din, dout, cus, g);
     return 0;
 }
