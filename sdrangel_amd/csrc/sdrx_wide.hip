@@ -4,8 +4,8 @@
 //   sdrx_decim24_*      Decimators<qint32, qint16, 24, {8,12,16}>::decimate{1..64}_{cen,inf,sup}   int16 in, Sample{int32,int32} out
 //   sdrx_chan24_bank_*  N DownChannelizer stage chains (order 48) on Sample{int32,int32}, final `/= (1 << n)`
 // Accumulators reach 2^38 in this build, so the packed-int16 dot2 kernels of the 16-bit flavour do not carry over: this is a
-// plain, exact 64-bit implementation -- one generic kernel, runtime stage modes, no sharing of stages between channels --
-// offered for completeness of the build switch, not tuned.
+// plain, exact 64-bit implementation -- one generic kernel, runtime stage modes, the channels' common stages evaluated once --
+// offered for completeness of the build switch, not tuned like the 16-bit path.
 // Semantics kept (all pinned against the reference's 24-bit build, oracle/ref_shim24.cpp): int64 pair sums and products,
 // the centre tap `((int32_t) x) << 11` as an INT shift that wraps at 32 bits (inthalfbandfiltereo.h:818-827,858-867),
 // `acc >> 11` narrowed to int32, rotations with int32 negation, whole groups / dropped tail for the decimators, carried
@@ -29,13 +29,14 @@ constexpr int W_NT = 256;
 constexpr int W_MAXS = 6;              // stages per pass
 constexpr int W_H = 64;                // history entries in front of every stage array (62 needed)
 
-struct WJob {                          // one stream through one pass
+struct WJob {                          // one segment of the stage trie: <= 6 stages on one stream
     const int32_t* hist;               // W_HIST samples (int32 pairs; int16 pairs when in16) in front of t_old
     const void* in;                    // new samples [t_old, t_new)
-    int32_t* out;                      // element 0 <-> absolute output index o_base
+    int32_t* out;                      // the segment's output as a stream for deeper segments (nullptr: none); element 0 <-> o_base
+    int32_t* out2;                     // the same samples as a channel / decimator result: >> post, or / (1 << div_log2) (nullptr: none)
     long t_old, t_new, o_base;
     long c_first, c_last;              // absolute chunk range to compute
-    int n_stages, in16, pre, post, div_log2, cps;
+    int n_stages, in16, pre, post, div_log2, cps, warm;
     int mode[W_MAXS];
 };
 
@@ -72,7 +73,7 @@ void wide_pass_kernel(const WJob* __restrict__ jobs)
     for (int i = tid; i < w_lds(); i += W_NT) lds[i] = 0;
     __syncthreads();
     const long o_lo = jb.t_old >> L, o_hi = jb.t_new >> L;
-    for (long chunk = first - W_WARM; chunk <= last; ++chunk) {
+    for (long chunk = first - jb.warm; chunk <= last; ++chunk) {
         // ---- input chunk -> stage-1 array (entry W_H + j <-> relative sample j)
         {
             int* aI = lds + w_off(1), *aQ = aI + w_arr(1);
@@ -90,13 +91,17 @@ void wide_pass_kernel(const WJob* __restrict__ jobs)
                         re = v.x; im = v.y;
                     }
                 }
-                aI[W_H + j] = re; aQ[W_H + j] = im;
+                // arrays hold ROTATED stage inputs (what storeSample keeps): each array has one consumer stage, so the
+                // rotation is applied once where the sample is produced, not at each of the 2P + 1 reads of the FIR
+                int xr, xi;
+                w_rot(jb.mode[0], j, re, im, xr, xi);
+                aI[W_H + j] = xr; aQ[W_H + j] = xi;
             }
         }
         __syncthreads();
         const bool live = chunk >= first;
         for (int s = 1; s <= L; s++) {
-            const int nout = W_CHUNK >> s, mode = jb.mode[s - 1];
+            const int nout = W_CHUNK >> s;
             const int* iI = lds + w_off(s), *iQ = iI + w_arr(s);
             int* oI = lds + w_off(s + 1), *oQ = oI + w_arr(s + 1);
             for (int k = tid; k < nout; k += W_NT) {
@@ -105,28 +110,26 @@ void wide_pass_kernel(const WJob* __restrict__ jobs)
 #pragma unroll 4
                 for (int i = 0; i < P; i++) {
                     const int ja = M - 2 * i, jbb = M - (ORDER - 2) + 2 * i;
-                    int ar, ai, br, bi;
-                    w_rot(mode, ja, iI[W_H + ja], iQ[W_H + ja], ar, ai);
-                    w_rot(mode, jbb, iI[W_H + jbb], iQ[W_H + jbb], br, bi);
                     const long c = hb_c<ORDER>(i);
-                    aR += ((long)ar + (long)br) * c;
-                    aIm += ((long)ai + (long)bi) * c;
+                    aR += ((long)iI[W_H + ja] + (long)iI[W_H + jbb]) * c;
+                    aIm += ((long)iQ[W_H + ja] + (long)iQ[W_H + jbb]) * c;
                 }
                 const int jc = M - (ORDER / 2 - 1);
-                int cr, ci;
-                w_rot(mode, jc, iI[W_H + jc], iQ[W_H + jc], cr, ci);
-                aR += (long)(int)((uint32_t)cr << (HB_SHIFT - 1));          // ((int32_t) x) << 11: wraps at 32 bits, then widens
-                aIm += (long)(int)((uint32_t)ci << (HB_SHIFT - 1));
+                aR += (long)(int)((uint32_t)iI[W_H + jc] << (HB_SHIFT - 1));   // ((int32_t) x) << 11: wraps at 32 bits, then widens
+                aIm += (long)(int)((uint32_t)iQ[W_H + jc] << (HB_SHIFT - 1));
                 const int yr = (int)(uint32_t)(unsigned long)(aR >> (HB_SHIFT - 1));
                 const int yi = (int)(uint32_t)(unsigned long)(aIm >> (HB_SHIFT - 1));
-                if (s < L) { oI[W_H + k] = yr; oQ[W_H + k] = yi; }
+                if (s < L) { int xr, xi; w_rot(jb.mode[s], k, yr, yi, xr, xi); oI[W_H + k] = xr; oQ[W_H + k] = xi; }
                 else if (live) {
                     const long ao = chunk * nout + k;                      // absolute output index
                     if (ao >= o_lo && ao < o_hi) {
-                        int vr, vi;
-                        if (jb.div_log2 >= 0) { const int d = 1 << jb.div_log2; vr = yr / d; vi = yi / d; }   // s.m_real /= (1 << n)
-                        else { vr = yr >> jb.post; vi = yi >> jb.post; }
-                        reinterpret_cast<int2*>(jb.out)[ao - jb.o_base] = make_int2(vr, vi);
+                        if (jb.out) reinterpret_cast<int2*>(jb.out)[ao - jb.o_base] = make_int2(yr, yi);
+                        if (jb.out2) {
+                            int vr, vi;
+                            if (jb.div_log2 >= 0) { const int d = 1 << jb.div_log2; vr = yr / d; vi = yi / d; }   // s.m_real /= (1 << n)
+                            else { vr = yr >> jb.post; vi = yi >> jb.post; }
+                            reinterpret_cast<int2*>(jb.out2)[ao - jb.o_base] = make_int2(vr, vi);
+                        }
                     }
                 }
             }
@@ -165,22 +168,26 @@ __global__ void wide_shift_kernel(const int16_t* __restrict__ in, int32_t* __res
     if (i < n) out[i] = (int32_t)((uint32_t)(int32_t)in[i] << pre);
 }
 
-// one chain = a list of passes of <= 6 stages; pass p reads stream p (p = 0: the raw input) and writes stream p + 1
-struct WPassState { int n_stages = 0; int mode[W_MAXS] = { 0 }; void* hist[2] = { nullptr, nullptr }; int cur = 0; DevBuf out; };
-struct WChain {
-    int n = 0; uint8_t modes[32] = { 0 };
-    int32_t out_rate = 0, ofs = 0;
-    std::vector<WPassState> pass;                   // pass[0] uses the engine's shared raw history unless the chain owns it
-    long last_n = 0;
-};
+// The channels' stage strings form a trie (as in the 16-bit bank); it is cut into SEGMENTS: maximal runs of <= 6 stages without
+// a branch and without a channel ending inside.  A segment is one kernel job; segments whose input is ready run in the same
+// launch ("round" = number of segments between the raw stream and the job), blockIdx.y = job.  A segment's output is kept as a
+// stream (new samples + W_HIST samples of history) when deeper segments read it, and/or as channel result (divided by 2^n).
+struct WStream { DevBuf out; void* hist[2] = { nullptr, nullptr }; int cur = 0; int depth = 0; bool feeds = false; };
+struct WSeg { int in_stream = 0, out_stream = -1; int n_stages = 0; int mode[W_MAXS] = { 0 }; int round = 1; int depth_out = 0;
+              bool ends = false; DevBuf res; long last_n = 0; };
+struct WTrieNode { int child[3] = { -1, -1, -1 }; int depth = 0; bool ends = false; int seg = -1; };
+struct WChain { int n = 0; uint8_t modes[32] = { 0 }; int32_t out_rate = 0, ofs = 0; int seg = -1; };
 
 struct WEngine {
     int device = 0, order = 64, cus = 256;
     hipStream_t stream = nullptr;
     long T = 0;                                      // raw samples consumed since reset
     bool in16 = false; int pre = 0, post = 0;
-    void* raw_hist[2] = { nullptr, nullptr }; int raw_cur = 0;
     std::vector<WChain> chains;
+    std::vector<WStream> streams;                    // [0] = the raw input
+    std::vector<WSeg> segs;
+    int max_round = 0;
+    long pass_n = 0;                                 // what the last feed was (pass-through channels)
     DevBuf d_in;
     // job tables: pinned + device
     void* h_tab = nullptr; void* d_tab = nullptr; size_t tab_cap = 0; hipEvent_t tab_ev = nullptr;
@@ -195,8 +202,8 @@ int w_alloc_hist(void** p, size_t bytes, hipStream_t s)
 
 void w_free(WEngine* e)
 {
-    for (int i = 0; i < 2; i++) if (e->raw_hist[i]) (void)hipFree(e->raw_hist[i]);
-    for (auto& c : e->chains) for (auto& p : c.pass) { for (int i = 0; i < 2; i++) if (p.hist[i]) (void)hipFree(p.hist[i]); p.out.release(); }
+    for (auto& st : e->streams) { for (int i = 0; i < 2; i++) if (st.hist[i]) (void)hipFree(st.hist[i]); st.out.release(); }
+    for (auto& sg : e->segs) sg.res.release();
     e->d_in.release();
     if (e->h_tab) (void)hipHostFree(e->h_tab);
     if (e->d_tab) (void)hipFree(e->d_tab);
@@ -209,24 +216,72 @@ int w_init(WEngine* e, int device)
     e->device = device; e->cus = device_cu_count(device);
     SDRX_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     SDRX_HIP(hipEventCreateWithFlags(&e->tab_ev, hipEventDisableTiming));
-    e->tab_cap = 64 * 1024;
-    SDRX_HIP(hipHostMalloc(&e->h_tab, e->tab_cap, hipHostMallocDefault));
-    SDRX_HIP(hipMalloc(&e->d_tab, e->tab_cap));
-    const size_t raw_bytes = (size_t)W_HIST * (e->in16 ? 4 : 8);
-    for (int i = 0; i < 2; i++) { int rc = w_alloc_hist(&e->raw_hist[i], raw_bytes, e->stream); if (rc) return rc; }
     return SDRX_OK;
 }
 
-int w_add_chain(WEngine* e, int n, const uint8_t* modes)
+void w_add_chain(WEngine* e, int n, const uint8_t* modes)
 {
     WChain c; c.n = n; if (n) std::memcpy(c.modes, modes, (size_t)n);
-    for (int base = 0; base < n; base += W_MAXS) {
-        WPassState p; p.n_stages = n - base < W_MAXS ? n - base : W_MAXS;
-        for (int i = 0; i < p.n_stages; i++) p.mode[i] = modes[base + i];
-        if (base > 0) for (int i = 0; i < 2; i++) { int rc = w_alloc_hist(&p.hist[i], (size_t)W_HIST * 8, e->stream); if (rc) return rc; }
-        c.pass.push_back(std::move(p));
+    e->chains.push_back(c);
+}
+
+// trie -> segments -> streams; allocates the histories
+int w_plan(WEngine* e)
+{
+    std::vector<WTrieNode> trie(1);
+    std::vector<int> end_node(e->chains.size(), 0);
+    for (size_t c = 0; c < e->chains.size(); c++) {
+        int id = 0;
+        for (int s = 0; s < e->chains[c].n; s++) {
+            const int m = e->chains[c].modes[s];
+            if (trie[(size_t)id].child[m] < 0) { WTrieNode nn; nn.depth = s + 1; trie.push_back(nn); trie[(size_t)id].child[m] = (int)trie.size() - 1; }
+            id = trie[(size_t)id].child[m];
+        }
+        if (e->chains[c].n) trie[(size_t)id].ends = true;
+        end_node[c] = id;
     }
-    e->chains.push_back(std::move(c));
+    e->streams.clear(); e->segs.clear(); e->max_round = 0;
+    { WStream raw; raw.depth = 0; raw.feeds = true; e->streams.push_back(std::move(raw)); }
+    struct Todo { int node, stream, round; };
+    std::vector<Todo> todo{ Todo{ 0, 0, 0 } };
+    for (size_t ti = 0; ti < todo.size(); ti++) {
+        const Todo t = todo[ti];
+        for (int m = 0; m < 3; m++) {
+            int id = trie[(size_t)t.node].child[m];
+            if (id < 0) continue;
+            WSeg sg; sg.in_stream = t.stream; sg.round = t.round + 1; sg.n_stages = 0;
+            int mode = m;
+            for (;;) {
+                sg.mode[sg.n_stages++] = mode;
+                int kids = 0, only = -1, only_mode = 0;
+                for (int k = 0; k < 3; k++) if (trie[(size_t)id].child[k] >= 0) { kids++; only = trie[(size_t)id].child[k]; only_mode = k; }
+                if (kids != 1 || trie[(size_t)id].ends || sg.n_stages == W_MAXS) break;
+                id = only; mode = only_mode;
+            }
+            sg.depth_out = trie[(size_t)id].depth;
+            sg.ends = trie[(size_t)id].ends;
+            bool has_kids = false;
+            for (int k = 0; k < 3; k++) has_kids = has_kids || trie[(size_t)id].child[k] >= 0;
+            if (has_kids) {
+                WStream st; st.depth = sg.depth_out; st.feeds = true;
+                sg.out_stream = (int)e->streams.size();
+                e->streams.push_back(std::move(st));
+                todo.push_back(Todo{ id, sg.out_stream, sg.round });
+            }
+            trie[(size_t)id].seg = (int)e->segs.size();
+            if (sg.round > e->max_round) e->max_round = sg.round;
+            e->segs.push_back(std::move(sg));
+        }
+    }
+    for (size_t c = 0; c < e->chains.size(); c++) e->chains[c].seg = e->chains[c].n ? trie[(size_t)end_node[c]].seg : -1;
+    for (size_t i = 0; i < e->streams.size(); i++) {
+        const size_t bytes = (size_t)W_HIST * ((i == 0 && e->in16) ? 4 : 8);
+        for (int k = 0; k < 2; k++) { int rc = w_alloc_hist(&e->streams[i].hist[k], bytes, e->stream); if (rc) return rc; }
+    }
+    const size_t need = (e->segs.size() + 1) * sizeof(WJob) + (e->streams.size() + 1) * sizeof(WHistJob) + 256;
+    e->tab_cap = need < 64 * 1024 ? 64 * 1024 : need;
+    SDRX_HIP(hipHostMalloc(&e->h_tab, e->tab_cap, hipHostMallocDefault));
+    SDRX_HIP(hipMalloc(&e->d_tab, e->tab_cap));
     return SDRX_OK;
 }
 
@@ -234,72 +289,81 @@ int w_reset(WEngine* e)
 {
     SDRX_HIP(hipStreamSynchronize(e->stream));
     e->T = 0;
-    SDRX_HIP(hipMemsetAsync(e->raw_hist[e->raw_cur], 0, (size_t)W_HIST * (e->in16 ? 4 : 8), e->stream));
-    for (auto& c : e->chains) { c.last_n = 0; for (auto& p : c.pass) if (p.hist[p.cur]) SDRX_HIP(hipMemsetAsync(p.hist[p.cur], 0, (size_t)W_HIST * 8, e->stream)); }
+    for (size_t i = 0; i < e->streams.size(); i++)
+        SDRX_HIP(hipMemsetAsync(e->streams[i].hist[e->streams[i].cur], 0, (size_t)W_HIST * ((i == 0 && e->in16) ? 4 : 8), e->stream));
+    for (auto& sg : e->segs) sg.last_n = 0;
+    e->pass_n = 0;
     return SDRX_OK;
 }
 
-// feed n raw samples (device pointer) through every chain; outputs land in each chain's last pass buffer
+// feed n raw samples (device pointer) through every segment; results land in the segments' `res` buffers
 int w_feed(WEngine* e, const void* d_in, long n)
 {
     if (n <= 0) return SDRX_OK;
     const long T0 = e->T, T1 = e->T + n;
-    size_t max_pass = 0;
-    for (auto& c : e->chains) max_pass = c.pass.size() > max_pass ? c.pass.size() : max_pass;
-    const size_t nch = e->chains.size();
     SDRX_HIP(hipEventSynchronize(e->tab_ev));
-    if ((nch * (max_pass ? max_pass : 1)) * (sizeof(WJob) + sizeof(WHistJob)) + sizeof(WHistJob) > e->tab_cap) { set_error("too many chains for the job table"); return SDRX_EINVAL; }
     char* hp = static_cast<char*>(e->h_tab); char* dp = static_cast<char*>(e->d_tab);
     size_t used = 0;
     struct Launch { size_t off; int count; long max_segs; bool hist; };
     std::vector<Launch> launches;
-    for (size_t p = 0; p < max_pass; p++) {
+    for (int r = 1; r <= e->max_round; r++) {
         WJob* jobs = reinterpret_cast<WJob*>(hp + used);
-        int cnt = 0; long max_segs = 0;
-        std::vector<WHistJob> hj;
-        for (auto& c : e->chains) {
-            if (p >= c.pass.size()) continue;
-            WPassState& ps = c.pass[p];
-            const int depth_in = (int)p * W_MAXS;                      // stages in front of this pass
-            const long t_old = T0 >> depth_in, t_new = T1 >> depth_in;
-            const long o_old = t_old >> ps.n_stages, o_new = t_new >> ps.n_stages;
-            int rc = ps.out.reserve((size_t)(o_new - o_old + 1) * 8); if (rc) return rc;
+        int cnt = 0; long max_segs = 0, njobs = 0;
+        for (auto& sg : e->segs) if (sg.round == r) njobs++;
+        for (auto& sg : e->segs) {
+            if (sg.round != r) continue;
+            WStream& in = e->streams[(size_t)sg.in_stream];
+            const long t_old = T0 >> in.depth, t_new = T1 >> in.depth;
+            const long o_old = t_old >> sg.n_stages, o_new = t_new >> sg.n_stages;
             WJob& j = jobs[cnt++];
             std::memset(&j, 0, sizeof j);
-            j.hist = static_cast<const int32_t*>(p == 0 ? e->raw_hist[e->raw_cur] : ps.hist[ps.cur]);
-            j.in = p == 0 ? d_in : c.pass[p - 1].out.p;
-            j.out = static_cast<int32_t*>(ps.out.p);
+            j.hist = static_cast<const int32_t*>(in.hist[in.cur]);
+            j.in = sg.in_stream == 0 ? d_in : in.out.p;
+            if (sg.out_stream >= 0) {
+                WStream& os = e->streams[(size_t)sg.out_stream];
+                int rc = os.out.reserve((size_t)(o_new - o_old + 1) * 8); if (rc) return rc;
+                j.out = static_cast<int32_t*>(os.out.p);
+            }
+            if (sg.ends) {
+                int rc = sg.res.reserve((size_t)(o_new - o_old + 1) * 8); if (rc) return rc;
+                j.out2 = static_cast<int32_t*>(sg.res.p);
+                sg.last_n = o_new - o_old;
+            }
             j.t_old = t_old; j.t_new = t_new; j.o_base = o_old;
             j.c_first = t_old / W_CHUNK; j.c_last = t_new > t_old ? (t_new - 1) / W_CHUNK : j.c_first - 1;
-            j.n_stages = ps.n_stages; j.in16 = (p == 0 && e->in16) ? 1 : 0; j.pre = e->pre;
-            const bool lastp = p + 1 == c.pass.size();
-            j.post = lastp ? e->post : 0;
-            j.div_log2 = (lastp && !e->in16) ? c.n : -1;               // channelizer: /(1 << n) on the final output; decimators: >> post
-            if (!lastp) j.div_log2 = -1;
-            for (int i = 0; i < ps.n_stages; i++) j.mode[i] = ps.mode[i];
+            j.n_stages = sg.n_stages; j.in16 = (sg.in_stream == 0 && e->in16) ? 1 : 0; j.pre = e->pre;
+            j.post = e->post;
+            j.div_log2 = e->in16 ? -1 : sg.depth_out;                  // channelizer: / (1 << n) on a channel's result; decimators: >> post
+            for (int i = 0; i < sg.n_stages; i++) j.mode[i] = sg.mode[i];
+            j.warm = (int)(((long)(e->order - 2) * ((1L << sg.n_stages) - 1) + W_CHUNK - 1) / W_CHUNK);
+            if (j.warm < 1) j.warm = 1;
             const long chunks = j.c_last - j.c_first + 1;
-            // segments: enough to fill the chip (4 per CU over all chains), but at least 8 chunks each where the feed has
-            // them -- every segment spends W_WARM chunks re-creating its filter state
-            const long target = (long)e->cus * 4 / (long)(nch ? nch : 1) + 1;
+            // segments of the time axis: enough to fill the chip (4 per CU over the jobs of this launch), but at least 8 chunks
+            // each where the feed has them -- every one spends `warm` chunks re-creating its filter state
+            const long target = (long)e->cus * 4 / (njobs ? njobs : 1) + 1;
             long cps = (chunks + target - 1) / target;
             if (cps < 8) cps = chunks < 8 ? chunks : 8;
             if (cps < 1) cps = 1;
             if (cps > 64) cps = 64;
             j.cps = (int)cps;
-            const long segs = chunks > 0 ? (chunks + cps - 1) / cps : 0;
-            if (segs > max_segs) max_segs = segs;
-            if (lastp) c.last_n = o_new - o_old;
-            if (p > 0) hj.push_back(WHistJob{ ps.hist[ps.cur], j.in, ps.hist[ps.cur ^ 1], t_new - t_old, 1 });
+            const long sgs = chunks > 0 ? (chunks + cps - 1) / cps : 0;
+            if (sgs > max_segs) max_segs = sgs;
         }
         launches.push_back(Launch{ used, cnt, max_segs, false });
         used += (size_t)cnt * sizeof(WJob);
-        if (p == 0) hj.push_back(WHistJob{ e->raw_hist[e->raw_cur], d_in, e->raw_hist[e->raw_cur ^ 1], n, e->in16 ? 0 : 1 });
-        if (!hj.empty()) {
-            std::memcpy(hp + used, hj.data(), hj.size() * sizeof(WHistJob));
-            launches.push_back(Launch{ used, (int)hj.size(), 0, true });
-            used += hj.size() * sizeof(WHistJob);
-        }
     }
+    {
+        WHistJob* hj = reinterpret_cast<WHistJob*>(hp + used);
+        int cnt = 0;
+        for (size_t i = 0; i < e->streams.size(); i++) {
+            WStream& st = e->streams[i];
+            const long nn = (T1 >> st.depth) - (T0 >> st.depth);
+            hj[cnt++] = WHistJob{ st.hist[st.cur], i == 0 ? d_in : st.out.p, st.hist[st.cur ^ 1], nn, (i == 0 && e->in16) ? 0 : 1 };
+        }
+        launches.push_back(Launch{ used, cnt, 0, true });
+        used += (size_t)cnt * sizeof(WHistJob);
+    }
+    if (used > e->tab_cap) { set_error("sdrx_wide: job table overflow"); return SDRX_EINVAL; }
     SDRX_HIP(hipMemcpyAsync(dp, hp, used, hipMemcpyHostToDevice, e->stream));
     SDRX_HIP(hipEventRecord(e->tab_ev, e->stream));
     for (const Launch& l : launches) {
@@ -311,9 +375,9 @@ int w_feed(WEngine* e, const void* d_in, long n)
         }
         SDRX_HIP(hipGetLastError());
     }
-    e->raw_cur ^= 1;
-    for (auto& c : e->chains) for (size_t p = 1; p < c.pass.size(); p++) c.pass[p].cur ^= 1;
+    for (auto& st : e->streams) st.cur ^= 1;
     e->T = T1;
+    e->pass_n = n;
     return SDRX_OK;
 }
 
@@ -351,7 +415,8 @@ int sdrx_decim24_create(sdrx_decim24_t** out, int device, int log2_decim, int fc
             }
             modes[s] = (uint8_t)m;
         }
-        rc = w_add_chain(&h->e, log2_decim, modes);
+        w_add_chain(&h->e, log2_decim, modes);
+        rc = w_plan(&h->e);
     }
     if (rc) { w_free(&h->e); delete h; return rc; }
     SDRX_HIP(hipStreamSynchronize(h->e.stream));
@@ -397,8 +462,7 @@ int sdrx_decim24_process(sdrx_decim24_t* h, const int16_t* iq, int32_t n_int16, 
         return SDRX_OK;
     }
     rc = w_feed(&h->e, h->e.d_in.p, n_cplx); if (rc) return rc;
-    WChain& c = h->e.chains[0];
-    SDRX_HIP(hipMemcpyAsync(out_iq, c.pass.back().out.p, (size_t)n_out * 8, hipMemcpyDeviceToHost, h->e.stream));
+    SDRX_HIP(hipMemcpyAsync(out_iq, h->e.segs[(size_t)h->e.chains[0].seg].res.p, (size_t)n_out * 8, hipMemcpyDeviceToHost, h->e.stream));
     SDRX_HIP(hipStreamSynchronize(h->e.stream));
     return SDRX_OK;
 }
@@ -419,7 +483,7 @@ int sdrx_decim24_process_dev(sdrx_decim24_t* h, const void* d_iq, int64_t n_cplx
         return SDRX_OK;
     }
     int rc = w_feed(&h->e, d_iq, (long)n_cplx); if (rc) return rc;
-    if (n_out > 0) SDRX_HIP(hipMemcpyAsync(d_out, h->e.chains[0].pass.back().out.p, (size_t)n_out * 8, hipMemcpyDeviceToDevice, h->e.stream));
+    if (n_out > 0) SDRX_HIP(hipMemcpyAsync(d_out, h->e.segs[(size_t)h->e.chains[0].seg].res.p, (size_t)n_out * 8, hipMemcpyDeviceToDevice, h->e.stream));
     return SDRX_OK;
 }
 
@@ -444,9 +508,10 @@ int sdrx_chan24_bank_create(sdrx_chan24_bank_t** out, int device, int32_t in_rat
     for (int c = 0; c < n_ch && !rc; c++) {
         uint8_t modes[32]; int32_t orate = 0, ofs = 0;
         const int n = sdrx_chan_plan(in_rate, req_rate[c], req_fc[c], modes, &orate, &ofs);     // the float bisection (downchannelizer.cpp:250-287)
-        rc = w_add_chain(&b->e, n, modes);
-        if (!rc) { b->e.chains.back().out_rate = orate; b->e.chains.back().ofs = ofs; }
+        w_add_chain(&b->e, n, modes);
+        b->e.chains.back().out_rate = orate; b->e.chains.back().ofs = ofs;
     }
+    if (!rc) rc = w_plan(&b->e);
     if (rc) { w_free(&b->e); delete b; return rc; }
     SDRX_HIP(hipStreamSynchronize(b->e.stream));
     *out = b;
@@ -484,12 +549,12 @@ int sdrx_chan24_bank_info(const sdrx_chan24_bank_t* b, int32_t c, int32_t* n_sta
 int sdrx_chan24_bank_feed(sdrx_chan24_bank_t* b, const int32_t* iq, int64_t n_cplx)
 {
     if (!b || n_cplx < 0 || (n_cplx > 0 && !iq)) { set_error("sdrx_chan24_bank_feed: bad argument"); return SDRX_EINVAL; }
-    if (n_cplx == 0) { for (auto& c : b->e.chains) c.last_n = 0; return SDRX_OK; }
+    if (n_cplx == 0) { for (auto& sg : b->e.segs) sg.last_n = 0; b->e.pass_n = 0; return SDRX_OK; }
     SDRX_HIP(hipSetDevice(b->e.device));
     SDRX_HIP(hipStreamSynchronize(b->e.stream));
     int rc = b->e.d_in.reserve((size_t)n_cplx * 8); if (rc) return rc;
     SDRX_HIP(hipMemcpyAsync(b->e.d_in.p, iq, (size_t)n_cplx * 8, hipMemcpyHostToDevice, b->e.stream));
-    for (auto& c : b->e.chains) if (c.n == 0) c.last_n = n_cplx;               // no stage: the input goes straight through (downchannelizer.cpp:57-60)
+    b->e.pass_n = n_cplx;                                                      // no stage: the input goes straight through (downchannelizer.cpp:57-60)
     return w_feed(&b->e, b->e.d_in.p, (long)n_cplx);
 }
 
@@ -498,14 +563,14 @@ int sdrx_chan24_bank_feed(sdrx_chan24_bank_t* b, const int32_t* iq, int64_t n_cp
 int sdrx_chan24_bank_feed_dev(sdrx_chan24_bank_t* b, const void* d_iq, int64_t n_cplx)
 {
     if (!b || n_cplx < 0 || (n_cplx > 0 && !d_iq)) { set_error("sdrx_chan24_bank_feed_dev: bad argument"); return SDRX_EINVAL; }
-    if (n_cplx == 0) { for (auto& c : b->e.chains) c.last_n = 0; return SDRX_OK; }
+    if (n_cplx == 0) { for (auto& sg : b->e.segs) sg.last_n = 0; b->e.pass_n = 0; return SDRX_OK; }
     SDRX_HIP(hipSetDevice(b->e.device));
-    for (auto& c : b->e.chains) if (c.n == 0) {
+    for (auto& c : b->e.chains) if (c.n == 0) {                                // a pass-through channel hands out a copy of the input
         int rc = b->e.d_in.reserve((size_t)n_cplx * 8); if (rc) return rc;
         SDRX_HIP(hipMemcpyAsync(b->e.d_in.p, d_iq, (size_t)n_cplx * 8, hipMemcpyDeviceToDevice, b->e.stream));
         break;
     }
-    for (auto& c : b->e.chains) if (c.n == 0) c.last_n = n_cplx;
+    b->e.pass_n = n_cplx;
     return w_feed(&b->e, d_iq, (long)n_cplx);
 }
 
@@ -513,8 +578,8 @@ int sdrx_chan24_bank_out_dev(sdrx_chan24_bank_t* b, int32_t c, const void** d_ou
 {
     if (!b || c < 0 || c >= (int32_t)b->e.chains.size() || !d_out || !n_cplx) { set_error("sdrx_chan24_bank_out_dev: bad argument"); return SDRX_EINVAL; }
     WChain& ch = b->e.chains[(size_t)c];
-    *d_out = ch.n == 0 ? b->e.d_in.p : ch.pass.back().out.p;
-    *n_cplx = ch.last_n;
+    *d_out = ch.n == 0 ? b->e.d_in.p : b->e.segs[(size_t)ch.seg].res.p;
+    *n_cplx = ch.n == 0 ? b->e.pass_n : b->e.segs[(size_t)ch.seg].last_n;
     return SDRX_OK;
 }
 
@@ -531,9 +596,10 @@ int64_t sdrx_chan24_bank_read(sdrx_chan24_bank_t* b, int32_t c, int32_t* out_iq,
     if (!b || c < 0 || c >= (int32_t)b->e.chains.size() || cap < 0 || (cap > 0 && !out_iq)) { set_error("sdrx_chan24_bank_read: bad argument"); return SDRX_EINVAL; }
     if (hipSetDevice(b->e.device) != hipSuccess) return SDRX_EHIP;
     WChain& ch = b->e.chains[(size_t)c];
-    const int64_t n = ch.last_n < cap ? ch.last_n : cap;
+    const int64_t have = ch.n == 0 ? b->e.pass_n : b->e.segs[(size_t)ch.seg].last_n;
+    const int64_t n = have < cap ? have : cap;
     if (n <= 0) return 0;
-    const void* src = ch.n == 0 ? b->e.d_in.p : ch.pass.back().out.p;
+    const void* src = ch.n == 0 ? b->e.d_in.p : b->e.segs[(size_t)ch.seg].res.p;
     hipError_t e = hipMemcpyAsync(out_iq, src, (size_t)n * 8, hipMemcpyDeviceToHost, b->e.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->e.stream);
     if (e != hipSuccess) return hip_fail(e, "sdrx_chan24_bank_read", __FILE__, __LINE__);

@@ -264,8 +264,10 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                         constexpr int dd = (r + 1) >> 1;
                         const int aI = dot2(vI[dd], (r & 1) ? oc.y : oc.x, sI[r]);
                         const int aQ = dot2(vQ[dd], (r & 1) ? oc.w : oc.z, sQ[r]);
-                        yI[r] = (int)(int16_t)(aI >> (HB_SHIFT - 1));               // Sample::setReal (:828)
-                        yQ[r] = (int)(int16_t)(aQ >> (HB_SHIFT - 1));
+                        // Sample::setReal (:828) keeps the low 16 bits: every store below (arms, node streams) takes just those,
+                        // so the sign extension is left to the one consumer that needs the value (the channel end's division)
+                        yI[r] = aI >> (HB_SHIFT - 1);
+                        yQ[r] = aQ >> (HB_SHIFT - 1);
                     });
                     auto alt = [](uint32_t v) { return ((0u - v) & 0xffffu) | (v & 0xffff0000u); };   // arm entry m even (low half): wrap-negated
                     if ((int)o0.x >= 0) {                                          // own arms for the children
@@ -318,13 +320,13 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                             if (rel >= 0 && rel + R <= span) {                     // whole job in range: no per-sample guards
 #pragma unroll
                                 for (int r = 0; r < R; r++)
-                                    dst[r] = sk.shift ? pack_iq(div_pow2_trunc(yI[r], sk.shift), div_pow2_trunc(yQ[r], sk.shift))
+                                    dst[r] = sk.shift ? pack_iq(div_pow2_trunc((int)(int16_t)yI[r], sk.shift), div_pow2_trunc((int)(int16_t)yQ[r], sk.shift))
                                                       : pack_iq(yI[r], yQ[r]);
                             } else if (rel > -R && rel < span) {
 #pragma unroll
                                 for (int r = 0; r < R; r++)
                                     if (rel + r >= 0 && rel + r < span)
-                                        dst[r] = sk.shift ? pack_iq(div_pow2_trunc(yI[r], sk.shift), div_pow2_trunc(yQ[r], sk.shift))
+                                        dst[r] = sk.shift ? pack_iq(div_pow2_trunc((int)(int16_t)yI[r], sk.shift), div_pow2_trunc((int)(int16_t)yQ[r], sk.shift))
                                                           : pack_iq(yI[r], yQ[r]);
                             }
                             si = sk.next;

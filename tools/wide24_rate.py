@@ -40,7 +40,7 @@ b.sync()
 dt = (time.perf_counter() - t) / 3
 res["chan24_32ch_61.44M_to_48k_GSps"] = m / dt / 1e9
 b.close()
-res["note"] = "plain 64-bit kernel, no stage sharing between channels; inputs in HBM; 1 GPU"
+res["note"] = "plain 64-bit kernel, stages shared between channels (trie of <= 6-stage segments); inputs in HBM; 1 GPU"
 print(json.dumps(res))
 if len(sys.argv) > 1:
     json.dump(res, open(sys.argv[1], "w"), indent=1)
