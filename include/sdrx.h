@@ -407,6 +407,14 @@ int sdrx_fdecim_sync(sdrx_fdecim_t* h);
 int sdrx_fdecim_set_stream(sdrx_fdecim_t* h, void* hip_stream);
 /* input elements per loop iteration of the reference method (its `pos +=` stride) */
 int32_t sdrx_fdecim_group(int log2_decim, int fcpos);
+/* the six IntHalfbandFilterEOF members that all decimateK_x of one DecimatorsFI / FF / IF object share (cascade stage s is
+ * member s in every variant): same protocol as sdrx_decim_save_stages / _load_stages.  The float handles carry their filters'
+ * rings explicitly, so both calls are plain device copies. */
+typedef struct sdrx_fdecim_stages sdrx_fdecim_stages_t;
+int sdrx_fdecim_stages_create(sdrx_fdecim_stages_t** s, int device);
+int sdrx_fdecim_stages_destroy(sdrx_fdecim_stages_t* s);
+int sdrx_fdecim_save_stages(sdrx_fdecim_t* h, sdrx_fdecim_stages_t* s);
+int sdrx_fdecim_load_stages(sdrx_fdecim_t* h, const sdrx_fdecim_stages_t* s);
 int sdrx_fdecim_set_timing(sdrx_fdecim_t* h, int enabled);
 int sdrx_fdecim_get_timing(sdrx_fdecim_t* h, double* total_ms, int64_t* launches, int reset);
 int sdrx_fdecim_last_launch(const sdrx_fdecim_t* h, char* kernel_name, int name_cap, int* grid, int* block, int* lds_bytes);

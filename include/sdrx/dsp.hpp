@@ -13,7 +13,7 @@
 // (K, fcPos) pair is a handle (created on first use) and the object carries a sdrx_decim_stages_t: when a call names another
 // variant than the previous one, the old handle's filters are saved into it and the new handle continues from them
 // (sdrx_decim_save_stages / sdrx_decim_load_stages), so a change of K or fcPos at run time gives the reference object's
-// samples, leftovers of the other cascade included.  (DecimatorsFI/FF/IF below still keep one state per variant.)
+// samples, leftovers of the other cascade included.  DecimatorsFI / FF / IF below do the same with sdrx_fdecim_*_stages.
 // Visible difference: DSP calls still return void -- a failing GPU call is logged to stderr and the output iterator does
 // not advance (the reference has no error path at all on these calls).
 #pragma once
@@ -153,12 +153,12 @@ struct FSample {
 static_assert(sizeof(FSample) == 8, "FSample must be {float re, float im}");
 typedef std::vector<FSample> FSampleVector;
 
-// shared body: one handle per (K, fcPos) method, created on first use (as Decimators above)
+// shared body: one handle per (K, fcPos) method, created on first use, all on one shared filter set (as Decimators above)
 template<typename OutVec, typename InT, int IN_KIND, int OUT_KIND, int BITS>
 class FloatDecimatorsBase {
 public:
-    explicit FloatDecimatorsBase(int device = 0) : m_device(device) { for (auto& row : m_h) for (auto& h : row) h = nullptr; }
-    ~FloatDecimatorsBase() { for (auto& row : m_h) for (auto& h : row) if (h) sdrx_fdecim_destroy(h); }
+    explicit FloatDecimatorsBase(int device = 0) : m_device(device), m_stages(nullptr), m_last(nullptr) { for (auto& row : m_h) for (auto& h : row) h = nullptr; }
+    ~FloatDecimatorsBase() { for (auto& row : m_h) for (auto& h : row) if (h) sdrx_fdecim_destroy(h); if (m_stages) sdrx_fdecim_stages_destroy(m_stages); }
     FloatDecimatorsBase(const FloatDecimatorsBase&) = delete;
     FloatDecimatorsBase& operator=(const FloatDecimatorsBase&) = delete;
     void decimate1(typename OutVec::iterator* it, const InT* buf, int32_t nbIAndQ) { run(0, SDRX_FC_CEN, it, buf, nbIAndQ); }
@@ -175,12 +175,21 @@ private:
         if (!h && sdrx_fdecim_create(&h, m_device, log2, fcpos, IN_KIND, OUT_KIND, BITS) != SDRX_OK) {
             std::fprintf(stderr, "sdrx float decimators: %s\n", sdrx_last_error()); h = nullptr; return;
         }
+        if (h != m_last) {                                 // another cascade on the object's six filters (decimatorsfi.h: m_decimator2 .. 64)
+            if (!m_stages && sdrx_fdecim_stages_create(&m_stages, m_device) != SDRX_OK) { std::fprintf(stderr, "sdrx float decimators: %s\n", sdrx_last_error()); return; }
+            if ((m_last && sdrx_fdecim_save_stages(m_last, m_stages) != SDRX_OK) || sdrx_fdecim_load_stages(h, m_stages) != SDRX_OK) {
+                std::fprintf(stderr, "sdrx float decimators: %s\n", sdrx_last_error()); return;
+            }
+            m_last = h;
+        }
         int32_t cnt = 0;
         if (sdrx_fdecim_process(h, buf, n, &**it, &cnt) != SDRX_OK) { std::fprintf(stderr, "sdrx float decimators: %s\n", sdrx_last_error()); return; }
         *it += cnt;
     }
     int m_device;
     sdrx_fdecim_t* m_h[7][3];
+    sdrx_fdecim_stages_t* m_stages;
+    sdrx_fdecim_t* m_last;
 };
 // DecimatorsFI: float in, int16 Sample out (decimatorsfi.h:29-57; AirspyHF thread)
 class DecimatorsFI : public FloatDecimatorsBase<SampleVector, float, SDRX_FD_IN_F32, SDRX_FD_OUT_I16, 16> {

@@ -53,4 +53,20 @@ void producer_side_f(int device)
     FCASE(RefIF12, GpuIF12, FSampleVector, qint16, decimate16_cen, true, 4096)
     FCASE(RefIF12, GpuIF12, FSampleVector, qint16, decimate64_sup, true, 4096)
     FCASE(RefIF12, GpuIF12, FSampleVector, qint16, decimate4_inf, true, 4096)
+    {
+        // ONE DecimatorsFI object, the AirspyHF thread changes its decimation while running: the cascades share the object's filters
+        DecimatorsFI ref; sdrx::DecimatorsFI gpu(device);
+        int call = 0;
+        fcase<SampleVector, float>("DecimatorsFI: one object, K / fcPos changed at run time",
+              [&](SampleVector::iterator* it, const float* b, qint32 len) {
+                  switch (call) { case 0: ref.decimate64_cen(it, b, len); break; case 1: ref.decimate8_inf(it, b, len); break;
+                                  case 2: ref.decimate64_cen(it, b, len); break; case 3: ref.decimate2_sup(it, b, len); break;
+                                  default: ref.decimate16_sup(it, b, len); break; } },
+              [&](SampleVector::iterator* it, const float* b, qint32 len) {
+                  switch (call) { case 0: gpu.decimate64_cen(it, b, len); break; case 1: gpu.decimate8_inf(it, b, len); break;
+                                  case 2: gpu.decimate64_cen(it, b, len); break; case 3: gpu.decimate2_sup(it, b, len); break;
+                                  default: gpu.decimate16_sup(it, b, len); break; }
+                  call++; },
+              false, 0);
+    }
 }

@@ -131,6 +131,7 @@ typedef struct sdro_fdecim sdro_fdecim;
 sdro_fdecim* sdro_fdecim_new(int log2_decim, int fcpos, int in_kind, int out_kind, int input_bits);
 void    sdro_fdecim_free(sdro_fdecim*);
 void    sdro_fdecim_reset(sdro_fdecim*);
+void    sdro_fdecim_switch(sdro_fdecim*, int log2_decim, int fcpos);   /* next call: another decimateK_x on the same six filters */
 int32_t sdro_fdecim_process(sdro_fdecim*, const void* in, int32_t n_elems, void* out);
 int32_t sdro_fdecim_group(int log2_decim, int fcpos);      /* elements per loop iteration of the reference function */
 

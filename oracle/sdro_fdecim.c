@@ -60,6 +60,13 @@ sdro_fdecim* sdro_fdecim_new(int log2, int fcpos, int in_kind, int out_kind, int
 }
 void sdro_fdecim_free(sdro_fdecim* d) { free(d); }
 void sdro_fdecim_reset(sdro_fdecim* d) { memset(d->hist, 0, sizeof d->hist); }
+/* one DecimatorsFI / FF / IF object runs every decimateK_x on the same six filters (m_decimator2 .. m_decimator64): cascade
+ * stage s is member s whatever the variant, so another variant continues on what each filter saw last */
+void sdro_fdecim_switch(sdro_fdecim* d, int log2, int fcpos)
+{
+    d->log2 = log2; d->fcpos = fcpos;
+    d->n_stages = fcpos == SDRO_FC_CEN ? log2 : (log2 >= 3 ? log2 - 2 : 0);
+}
 
 int32_t sdro_fdecim_group(int log2, int fcpos)
 {

@@ -153,6 +153,10 @@ def lib() -> C.CDLL:
         "sdrx_decim_stages_destroy": (C.c_int, [vp]),
         "sdrx_decim_save_stages": (C.c_int, [vp, vp]),
         "sdrx_decim_load_stages": (C.c_int, [vp, vp]),
+        "sdrx_fdecim_stages_create": (C.c_int, [pp, C.c_int]),
+        "sdrx_fdecim_stages_destroy": (C.c_int, [vp]),
+        "sdrx_fdecim_save_stages": (C.c_int, [vp, vp]),
+        "sdrx_fdecim_load_stages": (C.c_int, [vp, vp]),
         "sdrx_decim24_process_dev": (C.c_int, [vp, vp, i64, vp, C.POINTER(i64)]),
         "sdrx_decim24_sync": (C.c_int, [vp]),
         "sdrx_chan24_bank_feed_dev": (C.c_int, [vp, vp, i64]),
@@ -382,6 +386,48 @@ class DecimatorsU(Decimators):
         n = C.c_int32()
         _check(lib().sdrx_decim_process_u8(self._h, buf.ctypes.data, buf.size, out.ctypes.data, C.byref(n)), "sdrx_decim_process_u8")
         return out[: 2 * n.value]
+
+
+class FloatDecimStages:
+    """The six IntHalfbandFilterEOF states that all decimateK_x of ONE DecimatorsFI / FF / IF object share."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        _check(lib().sdrx_fdecim_stages_create(C.byref(self._h), device), "sdrx_fdecim_stages_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sdrx_fdecim_stages_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
+class FloatDecimatorsObject:
+    """One reference DecimatorsFI ("fi") / FF ("ff") / IF ("if") object: any decimateK_x per call on the same six filters
+    (what include/sdrx/dsp.hpp's sdrx::DecimatorsFI etc. do in C++)."""
+
+    def __init__(self, kind: str, input_bits: int = 16, device: int = 0):
+        self.kind, self.bits, self.device = kind, input_bits, device
+        self._variants, self._stages, self._last = {}, FloatDecimStages(device), None
+
+    def decimate(self, log2: int, fcpos: int, buf) -> np.ndarray:
+        d = self._variants.get((log2, fcpos))
+        if d is None:
+            d = FloatDecimators(self.kind, log2, fcpos, self.bits, self.device)
+            self._variants[(log2, fcpos)] = d
+        if d is not self._last:
+            if self._last is not None:
+                _check(lib().sdrx_fdecim_save_stages(self._last._h, self._stages._h), "sdrx_fdecim_save_stages")
+            _check(lib().sdrx_fdecim_load_stages(d._h, self._stages._h), "sdrx_fdecim_load_stages")
+            self._last = d
+        return d.decimate(buf)
+
+    def close(self):
+        for d in self._variants.values():
+            d.close()
+        self._variants = {}
+        self._stages.close()
 
 
 class FloatDecimators:

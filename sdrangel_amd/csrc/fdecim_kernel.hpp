@@ -17,8 +17,11 @@
 //
 // Work decomposition = decim_chain_kernel's: the stream that enters stage 1 ("pre-samples") is cut into chunks of
 // 2048; a workgroup owns a segment of consecutive chunks and carries every stage's 32-entry arm history in LDS from
-// chunk to chunk; before its first chunk it replays warm-up chunks (>= 62 * (2^NS - 1) pre-samples: the chain's
-// memory), taken from the input in front of the segment or, for the first segment, from the handle's history buffer.
+// chunk to chunk.  The FIRST segment of a call starts from the handle's explicit filter state (`seed`: per stage the
+// 32 + 32 last inputs as odd / even arm, I and Q -- the contents of the reference filter's ring); every other segment
+// replays warm-up chunks (>= 62 * (2^NS - 1) pre-samples: the chain's memory) taken from the call's own input in front
+// of it; the workgroup that owns the last chunk writes the state at the end of the data to `dump`.  The state being the
+// filters' own rings, one DecimatorsFI object's cascades can hand it to each other (sdrx_fdecim_save/load_stages).
 // HBM: reads the input once (+ warm-up re-reads that hit L2/MALL), writes 1/2^L of it.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -38,6 +41,7 @@ __host__ __device__ constexpr int fd_arr(int s) { return FD_H + (FD_CHUNK >> s);
 __host__ __device__ constexpr int fd_off(int s) { int o = 0; for (int u = 1; u < s; u++) o += 4 * fd_arr(u); return o; }
 __host__ __device__ constexpr int fd_lds_floats(int ns) { return fd_off(ns + 1); }
 __host__ __device__ constexpr int fd_warm_chunks(int ns) { return (62 * ((1 << ns) - 1) + FD_CHUNK - 1) / FD_CHUNK; }
+constexpr int FD_STATE = 4 * FD_H;      // floats of one filter's state: oI, oQ, eI, eQ, 32 entries each, oldest first
 
 // raw element access: IN = 0 float I/Q, IN = 1 int16 I/Q (converted exactly; sums of the front end stay in int)
 template<int IN> struct FdIn;
@@ -175,7 +179,8 @@ __device__ __forceinline__ void fd_stage(const float* __restrict__ oI, const flo
 
 template<int NS, int IN>
 __global__ __launch_bounds__(FD_THREADS)
-void fdecim_chain_kernel(const float2* __restrict__ hist,   // fd_warm_chunks(NS) * FD_CHUNK pre-samples in front of the call
+void fdecim_chain_kernel(const float* __restrict__ seed,    // NS x FD_STATE floats: the filters' state in front of the call
+                         float* __restrict__ dump,          // same layout: the state behind the call's last pre-sample
                          const void* __restrict__ in, void* __restrict__ out,
                          long n_pre, long n_out, int n_chunks, int cps, int fe, int out_kind, float scale)
 {
@@ -183,27 +188,33 @@ void fdecim_chain_kernel(const float2* __restrict__ hist,   // fd_warm_chunks(NS
     constexpr int PPT = C / 2 / NT;                        // pre-sample PAIRS per lane per chunk (4)
     __shared__ __attribute__((aligned(16))) float lds[fd_lds_floats(NS)];
     const int tid = threadIdx.x;
-    const long first = (long)blockIdx.x * cps;
+    const long first = (long)blockIdx.x * cps;             // the host keeps cps >= WARM: only segment 0 reaches in front of the call
     long last = first + cps; if (last > n_chunks) last = n_chunks;
 
     for (int i = tid; i < fd_lds_floats(NS); i += NT) lds[i] = 0.0f;
+    __syncthreads();
+    if (blockIdx.x == 0) {
+#pragma unroll
+        for (int s = 1; s <= NS; s++) {
+            float* a = lds + fd_off(s);
+            for (int i = tid; i < FD_STATE; i += NT) a[(i / FD_H) * fd_arr(s) + (i % FD_H)] = seed[(s - 1) * FD_STATE + i];
+        }
+    }
 
     float2 pe[PPT], po[PPT];                               // even / odd pre-sample of each pair
     auto fetch = [&](long chunk) {
 #pragma unroll
         for (int j = 0; j < PPT; j++) {
-            const long g = chunk * C + 2 * (j * NT + tid);  // global pre-sample index of the pair's first member (may be < 0)
-            if (g < 0) { pe[j] = hist[(long)WARM * C + g]; po[j] = hist[(long)WARM * C + g + 1]; }
-            else {
-                pe[j] = g < n_pre ? fd_pre<IN>(in, g, fe) : make_float2(0.0f, 0.0f);
-                po[j] = g + 1 < n_pre ? fd_pre<IN>(in, g + 1, fe) : make_float2(0.0f, 0.0f);
-            }
+            const long g = chunk * C + 2 * (j * NT + tid);  // global pre-sample index of the pair's first member
+            pe[j] = g < n_pre ? fd_pre<IN>(in, g, fe) : make_float2(0.0f, 0.0f);
+            po[j] = g + 1 < n_pre ? fd_pre<IN>(in, g + 1, fe) : make_float2(0.0f, 0.0f);
         }
     };
-    fetch(first - WARM);
+    const long start = blockIdx.x == 0 ? 0 : first - WARM;
+    fetch(start);
     __syncthreads();
 
-    for (long chunk = first - WARM; chunk < last; ++chunk) {
+    for (long chunk = start; chunk < last; ++chunk) {
         {
             float* oI = lds + fd_off(1), *oQ = oI + fd_arr(1), *eI = oQ + fd_arr(1), *eQ = eI + fd_arr(1);
 #pragma unroll
@@ -248,6 +259,18 @@ void fdecim_chain_kernel(const float2* __restrict__ hist,   // fd_warm_chunks(NS
             __syncthreads();
         }
 
+        // the state behind the data: the FD_H arm entries that end at the call's last sample (a partial last chunk holds
+        // n_pre - chunk * C pre-samples = a whole number of outputs of every stage: the call is whole groups)
+        if (chunk == (long)n_chunks - 1) {
+            const long left = n_pre - chunk * C;
+#pragma unroll
+            for (int s = 1; s <= NS; s++) {
+                const int have = (int)(left >> s);         // entries this chunk put into each arm of stage s
+                const float* a = lds + fd_off(s);
+                for (int i = tid; i < FD_STATE; i += NT) dump[(s - 1) * FD_STATE + i] = a[(i / FD_H) * fd_arr(s) + have + (i % FD_H)];
+            }
+            __syncthreads();                               // the carry below overwrites entries 0..31, which a short chunk just read
+        }
         // carry: the last FD_H entries of every arm become the next chunk's history
 #pragma unroll
         for (int s = 1; s <= NS; s++) {
@@ -274,17 +297,6 @@ __global__ void fd_pointwise_kernel(const void* __restrict__ in, void* __restric
         (void)dec1;
         fd_store(out, k, v, out_kind, scale);
     }
-}
-
-// new history = last W pre-samples of (old history ++ this call's pre-samples)
-template<int IN>
-__global__ void fd_hist_update_kernel(const float2* __restrict__ old_hist, const void* __restrict__ in, float2* __restrict__ new_hist,
-                                      long n_pre, int W, int fe)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= W) return;
-    const long src = (long)i + n_pre - W;
-    new_hist[i] = src >= 0 ? fd_pre<IN>(in, src, fe) : old_hist[i + n_pre];
 }
 
 } // namespace sdrx

@@ -12,7 +12,7 @@ using namespace sdrx;
 
 namespace {
 
-typedef void (*fd_chain_fn)(const float2*, const void*, void*, long, long, int, int, int, int, float);
+typedef void (*fd_chain_fn)(const float*, float*, const void*, void*, long, long, int, int, int, int, float);
 
 template<int IN> fd_chain_fn chain_for(int ns)
 {
@@ -64,12 +64,12 @@ struct sdrx_fdecim {
     // all 256 lanes have work in every stage (4 / 2 / 1 outputs), where stages 4..6 of a single pass idle 1/2 .. 7/8 of them
     int ns1 = 0, ns2 = 0;
     fd_chain_fn chain2 = nullptr;
-    float2* d_hist2[2] = { nullptr, nullptr };
-    int hist2_len = 0, cur2 = 0;
     DevBuf d_mid;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    float2* d_hist[2] = { nullptr, nullptr };
-    int hist_len = 0, cur = 0;
+    // the carried state: the six filters' rings as arm histories (FD_STATE floats per stage, cascade order), double-buffered:
+    // a call's first workgroup reads one copy while its last one writes the other
+    float* d_state[2] = { nullptr, nullptr };
+    int cur = 0;
     DevBuf d_in, d_out;
     char last_name[96] = "";
     int last_grid = 0, last_block = 0, last_lds = 0;
@@ -93,46 +93,36 @@ static int launch(sdrx_fdecim* h, const void* d_in, long n_groups, void* d_out, 
         h->last_grid = (int)grid; h->last_block = block; h->last_lds = 0;
         return h->timer.end(h->stream);
     }
-    auto run_pass = [&](fd_chain_fn fn, int ns, const float2* hist, const void* in, void* out, long np, int fe, int out_kind, float scale, int* grid_out) -> int {
+    auto run_pass = [&](fd_chain_fn fn, int ns, int stage0, const void* in, void* out, long np, int fe, int out_kind, float scale, int* grid_out) -> int {
         const long n_chunks = (np + FD_CHUNK - 1) / FD_CHUNK;
         if (n_chunks > 0x7fffffffL / 4) { set_error("sdrx_fdecim: input too long for one call"); return SDRX_EINVAL; }
         const int warm = fd_warm_chunks(ns);
         const int lds = fd_lds_floats(ns) * 4;
         const int wg_per_cu = std::max(1, std::min(8, (160 * 1024) / std::max(lds, 1)));
-        const int cps = choose_cps(n_chunks, h->cus * wg_per_cu, warm);
+        const int cps = std::max(choose_cps(n_chunks, h->cus * wg_per_cu, warm), warm);      // later segments warm up inside the call
         const long segs = (n_chunks + cps - 1) / cps;
-        hipLaunchKernelGGL(fn, dim3((unsigned)segs), dim3(FD_THREADS), 0, h->stream, hist, in, out, np, np >> ns, (int)n_chunks, cps, fe, out_kind, scale);
+        hipLaunchKernelGGL(fn, dim3((unsigned)segs), dim3(FD_THREADS), 0, h->stream, h->d_state[h->cur] + stage0 * FD_STATE, h->d_state[h->cur ^ 1] + stage0 * FD_STATE,
+                           in, out, np, np >> ns, (int)n_chunks, cps, fe, out_kind, scale);
         SDRX_HIP(hipGetLastError());
         if (grid_out) *grid_out = (int)segs;
         return SDRX_OK;
     };
     int rc;
     if (h->ns2 == 0) {
-        rc = run_pass(h->chain, h->ns, h->d_hist[h->cur], d_in, d_out, n_pre, h->fe, h->out_kind, h->scale, &h->last_grid); if (rc) return rc;
+        rc = run_pass(h->chain, h->ns, 0, d_in, d_out, n_pre, h->fe, h->out_kind, h->scale, &h->last_grid); if (rc) return rc;
         snprintf(h->last_name, sizeof h->last_name, "fdecim_chain_kernel<%d,%d>", h->ns, h->in_kind);
         h->last_lds = fd_lds_floats(h->ns) * 4;
     } else {
         const long n_mid = n_pre >> h->ns1;
         rc = h->d_mid.reserve((size_t)std::max<long>(n_mid, 1) * sizeof(float2)); if (rc) return rc;
-        rc = run_pass(h->chain, h->ns1, h->d_hist[h->cur], d_in, h->d_mid.p, n_pre, h->fe, 1, 1.0f, &h->last_grid); if (rc) return rc;
-        rc = run_pass(h->chain2, h->ns2, h->d_hist2[h->cur2], h->d_mid.p, d_out, n_mid, FD_FE_ID, h->out_kind, h->scale, nullptr); if (rc) return rc;
+        rc = run_pass(h->chain, h->ns1, 0, d_in, h->d_mid.p, n_pre, h->fe, 1, 1.0f, &h->last_grid); if (rc) return rc;
+        rc = run_pass(h->chain2, h->ns2, h->ns1, h->d_mid.p, d_out, n_mid, FD_FE_ID, h->out_kind, h->scale, nullptr); if (rc) return rc;
         snprintf(h->last_name, sizeof h->last_name, "fdecim_chain_kernel<%d,%d> + <%d,0>", h->ns1, h->in_kind, h->ns2);
         h->last_lds = fd_lds_floats(h->ns1) * 4;
     }
     h->last_block = FD_THREADS;
     trc = h->timer.end(h->stream); if (trc) return trc;
-    const unsigned hg = (unsigned)((h->hist_len + 255) / 256);
-    if (h->in_kind == 0) hipLaunchKernelGGL(fd_hist_update_kernel<0>, dim3(hg), dim3(256), 0, h->stream, h->d_hist[h->cur], d_in, h->d_hist[h->cur ^ 1], n_pre, h->hist_len, h->fe);
-    else                 hipLaunchKernelGGL(fd_hist_update_kernel<1>, dim3(hg), dim3(256), 0, h->stream, h->d_hist[h->cur], d_in, h->d_hist[h->cur ^ 1], n_pre, h->hist_len, h->fe);
-    SDRX_HIP(hipGetLastError());
-    h->cur ^= 1;
-    if (h->ns2) {
-        const unsigned hg2 = (unsigned)((h->hist2_len + 255) / 256);
-        hipLaunchKernelGGL(fd_hist_update_kernel<0>, dim3(hg2), dim3(256), 0, h->stream, h->d_hist2[h->cur2], h->d_mid.p, h->d_hist2[h->cur2 ^ 1],
-                           n_pre >> h->ns1, h->hist2_len, (int)FD_FE_ID);
-        SDRX_HIP(hipGetLastError());
-        h->cur2 ^= 1;
-    }
+    h->cur ^= 1;                                           // (a handle only ever reads the stages of its own cascade)
     return SDRX_OK;
 }
 
@@ -173,15 +163,9 @@ int sdrx_fdecim_create(sdrx_fdecim_t** out, int device, int log2_decim, int fcpo
     hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
     h->stream = h->own_stream;
-    h->hist_len = h->ns ? fd_warm_chunks(h->ns1) * FD_CHUNK : 0;
-    h->hist2_len = h->ns2 ? fd_warm_chunks(h->ns2) * FD_CHUNK : 0;
-    for (int i = 0; i < 2 && h->hist2_len; i++) {
-        e = hipMalloc(reinterpret_cast<void**>(&h->d_hist2[i]), (size_t)h->hist2_len * sizeof(float2));
-        if (e != hipSuccess) { sdrx_fdecim_destroy(h); return hip_fail(e, "hipMalloc(hist2)", __FILE__, __LINE__); }
-    }
-    for (int i = 0; i < 2 && h->hist_len; i++) {
-        e = hipMalloc(reinterpret_cast<void**>(&h->d_hist[i]), (size_t)h->hist_len * sizeof(float2));
-        if (e != hipSuccess) { sdrx_fdecim_destroy(h); return hip_fail(e, "hipMalloc(hist)", __FILE__, __LINE__); }
+    for (int i = 0; i < 2; i++) {
+        e = hipMalloc(reinterpret_cast<void**>(&h->d_state[i]), (size_t)6 * FD_STATE * sizeof(float));
+        if (e != hipSuccess) { sdrx_fdecim_destroy(h); return hip_fail(e, "hipMalloc(state)", __FILE__, __LINE__); }
     }
     *out = h;
     return sdrx_fdecim_reset(h);
@@ -192,7 +176,7 @@ int sdrx_fdecim_destroy(sdrx_fdecim_t* h)
     if (!h) return SDRX_OK;
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-    for (int i = 0; i < 2; i++) { if (h->d_hist[i]) (void)hipFree(h->d_hist[i]); if (h->d_hist2[i]) (void)hipFree(h->d_hist2[i]); }
+    for (int i = 0; i < 2; i++) if (h->d_state[i]) (void)hipFree(h->d_state[i]);
     h->d_in.release(); h->d_out.release(); h->d_mid.release(); h->timer.release();
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -203,8 +187,7 @@ int sdrx_fdecim_reset(sdrx_fdecim_t* h)
 {
     if (!h) return SDRX_EINVAL;
     SDRX_HIP(hipSetDevice(h->device));
-    if (h->hist_len) SDRX_HIP(hipMemsetAsync(h->d_hist[h->cur], 0, (size_t)h->hist_len * sizeof(float2), h->stream));
-    if (h->hist2_len) SDRX_HIP(hipMemsetAsync(h->d_hist2[h->cur2], 0, (size_t)h->hist2_len * sizeof(float2), h->stream));
+    SDRX_HIP(hipMemsetAsync(h->d_state[h->cur], 0, (size_t)6 * FD_STATE * sizeof(float), h->stream));
     return SDRX_OK;
 }
 
@@ -282,6 +265,56 @@ int sdrx_fdecim_last_launch(const sdrx_fdecim_t* h, char* kernel_name, int name_
     if (grid) *grid = h->last_grid;
     if (block) *block = h->last_block;
     if (lds_bytes) *lds_bytes = h->last_lds;
+    return SDRX_OK;
+}
+
+} // extern "C"
+
+/* ---- one DecimatorsFI / FF / IF object, several decimateK_x: the shared six filters -------------------------------- */
+struct sdrx_fdecim_stages { int device = 0; float* d_state = nullptr; };
+
+extern "C" {
+
+int sdrx_fdecim_stages_create(sdrx_fdecim_stages_t** out, int device)
+{
+    if (!out) { set_error("sdrx_fdecim_stages_create: null out"); return SDRX_EINVAL; }
+    *out = nullptr;
+    int rc = check_device(device); if (rc) return rc;
+    SDRX_HIP(hipSetDevice(device));
+    sdrx_fdecim_stages* s = new (std::nothrow) sdrx_fdecim_stages;
+    if (!s) return SDRX_ENOMEM;
+    s->device = device;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_state), (size_t)6 * FD_STATE * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(s->d_state, 0, (size_t)6 * FD_STATE * sizeof(float));
+    if (e != hipSuccess) { if (s->d_state) (void)hipFree(s->d_state); delete s; return hip_fail(e, "sdrx_fdecim_stages_create", __FILE__, __LINE__); }
+    *out = s;
+    return SDRX_OK;
+}
+
+int sdrx_fdecim_stages_destroy(sdrx_fdecim_stages_t* s)
+{
+    if (!s) return SDRX_OK;
+    (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();
+    if (s->d_state) (void)hipFree(s->d_state);
+    delete s;
+    return SDRX_OK;
+}
+
+int sdrx_fdecim_save_stages(sdrx_fdecim_t* h, sdrx_fdecim_stages_t* s)
+{
+    if (!h || !s || h->device != s->device) { set_error("sdrx_fdecim_save_stages: bad argument (handle and stage set must live on one device)"); return SDRX_EINVAL; }
+    SDRX_HIP(hipSetDevice(h->device));
+    if (h->ns) SDRX_HIP(hipMemcpyAsync(s->d_state, h->d_state[h->cur], (size_t)h->ns * FD_STATE * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    SDRX_HIP(hipStreamSynchronize(h->stream));
+    return SDRX_OK;
+}
+
+int sdrx_fdecim_load_stages(sdrx_fdecim_t* h, const sdrx_fdecim_stages_t* s)
+{
+    if (!h || !s || h->device != s->device) { set_error("sdrx_fdecim_load_stages: bad argument (handle and stage set must live on one device)"); return SDRX_EINVAL; }
+    SDRX_HIP(hipSetDevice(h->device));
+    SDRX_HIP(hipMemcpyAsync(h->d_state[h->cur], s->d_state, (size_t)6 * FD_STATE * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     return SDRX_OK;
 }
 

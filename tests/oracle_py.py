@@ -47,6 +47,7 @@ def _sig_fdecim(L):
     L.sdro_fdecim_free.argtypes = [vp]; L.sdro_fdecim_reset.argtypes = [vp]
     L.sdro_fdecim_process.restype = i32; L.sdro_fdecim_process.argtypes = [vp, vp, i32, vp]
     L.sdro_fdecim_group.restype = i32; L.sdro_fdecim_group.argtypes = [C.c_int] * 2
+    L.sdro_fdecim_switch.argtypes = [vp, C.c_int, C.c_int]
 
 
 class FDecim:
@@ -68,6 +69,10 @@ class FDecim:
         out = np.zeros(buf.size + 8, np.int16 if self.ok == 0 else np.float32)
         n = self.L.sdro_fdecim_process(self.h, buf.ctypes.data, buf.size, out.ctypes.data)
         return out[: 2 * n]
+
+    def switch(self, log2, fcpos):
+        """the next call runs another decimateK_x of the same object (same six filters)"""
+        self.L.sdro_fdecim_switch(self.h, log2, fcpos)
 
 
 def _sig_float(L):

@@ -83,3 +83,44 @@ def test_deep_chain_three_passes():
     assert np.array_equal(bank.read(0), orc.Chain(modes).feed(x))
     m2, _, _ = orc.chan_plan(2_400_000, 48000, 123_456)
     assert np.array_equal(bank.read(1), orc.Chain(m2).feed(x))
+
+
+def test_round2_entry_points_refuse_bad_arguments_and_take_empty_calls():
+    """null handles / pointers, out-of-range channels and empty inputs on the entry points added in round 2"""
+    L = sa.lib()
+    out = np.zeros(64, np.int32); n = C.c_int32(); n64 = C.c_int64(); p = C.c_void_p()
+    # 24-bit flavour
+    d = sa.Decimators24(3, sa.FC_INF, 12)
+    assert d.decimate(np.zeros(0, np.int16)).size == 0
+    assert d.decimate(np.zeros(30, np.int16)).size == 0                      # shorter than one 32-int16 group of decimate8_inf
+    assert L.sdrx_decim24_process(d._h, None, 64, out.ctypes.data, C.byref(n)) == -1
+    assert L.sdrx_decim24_process(None, out.ctypes.data, 64, out.ctypes.data, C.byref(n)) == -1
+    assert L.sdrx_decim24_process_dev(d._h, None, 64, None, C.byref(n64)) == -1
+    b = sa.ChannelizerBank24(2_400_000, [48000, 2_400_000], [100_000, 0])     # second channel: no stage, pass-through
+    assert [o.size for o in b.feed(np.zeros(0, np.int32))] == [0, 0]
+    x = synth.noise24(3000, 5)
+    y = b.feed(x)
+    assert np.array_equal(y[1], x)                                            # pass-through hands the input back
+    assert L.sdrx_chan24_bank_read(b._h, 7, out.ctypes.data, 10) == -1
+    assert L.sdrx_chan24_bank_info(b._h, 2, None, None, None, None) == -1
+    assert L.sdrx_chan24_bank_feed(b._h, None, 10) == -1
+    assert L.sdrx_chan24_bank_out_dev(b._h, 0, None, C.byref(n64)) == -1
+    # shared stage states
+    g = sa.Decimators(4, sa.FC_CEN, 12); st = sa.DecimStages()
+    assert L.sdrx_decim_save_stages(None, st._h) == -1 and L.sdrx_decim_load_stages(g._h, None) == -1
+    assert L.sdrx_decim_stages_create(None, 0) == -1
+    g1 = sa.Decimators(0, sa.FC_CEN, 12)                                      # decimate1 has no stage: save / load are no-ops
+    g1.save_stages(st); g1.load_stages(st)
+    assert np.array_equal(g1.decimate(np.arange(8, dtype=np.int16)), (np.arange(8) << 4).astype(np.int16))
+    # batch, ring
+    assert L.sdrx_decim_process_dev_batch(None, 1, None, None, None, None) == -1
+    assert L.sdrx_decim_ring_create(g._h, 100, 1, 1) == -1                     # needs two slots
+    assert L.sdrx_decim_ring_acquire(g._h) in (None, 0)                        # no ring yet
+    # corrections, audio tail, IIR
+    assert L.sdrx_iqimb_create(C.byref(p), 0, 0) == -1
+    assert L.sdrx_audiotail_create(C.byref(p), 0, 0, None) == -1
+    assert L.sdrx_iir_create(C.byref(p), 0, 0, None) == -1
+    bad = (sa.IirCfg * 1)(); bad[0].order = 9
+    assert L.sdrx_iir_create(C.byref(p), 0, 1, bad) == -1
+    for h in (d, b, g, g1, st):
+        h.close()

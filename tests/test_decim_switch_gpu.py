@@ -84,3 +84,26 @@ def test_checkpoint_refused_while_on_loaded_stages():
     d.decimate(synth.mix(5000, 1, 2047, 0, 1))                      # past the hand-over: the input history is the state again
     assert sa.lib().sdrx_decim_get_state(d._h, buf.ctypes.data) == 0
     d.close(); st.close()
+
+
+@pytest.mark.parametrize("kind,bits", [("fi", 16), ("ff", 16), ("if", 12)])
+def test_float_decimators_variant_changes_on_one_object(kind, bits):
+    """DecimatorsFI / FF / IF: the six IntHalfbandFilterEOF members are shared by all cascades of an object as well
+    (oracle model pinned by tests/test_oracle_vs_ref.py::test_float_decimators_variant_switch)"""
+    rng = np.random.default_rng(31 + bits)
+    for trial in range(5):
+        obj = sa.FloatDecimatorsObject(kind, bits)
+        o = None
+        for seg in range(8):
+            log2 = int(rng.integers(0, 7)); fc = int(rng.integers(0, 3)) if log2 else 2
+            blk = int(rng.choice([16, 130, 2 * 777, 5000, 40000, 300000]))
+            x = rng.uniform(-0.95, 0.95, blk).astype(np.float32) if kind != "if" else rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), blk).astype(np.int16)
+            if o is None:
+                o = orc.FDecim(kind, log2, fc, bits)
+            else:
+                o.switch(log2, fc)
+            cut = (blk // 3) & ~1
+            got = np.concatenate([obj.decimate(log2, fc, x[:cut]), obj.decimate(log2, fc, x[cut:])])
+            want = np.concatenate([o.process(x[:cut]), o.process(x[cut:])])
+            assert got.size == want.size and np.array_equal(got.view(np.uint8), want.view(np.uint8)), (kind, trial, seg, log2, fc, blk)
+        obj.close()

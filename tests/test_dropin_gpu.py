@@ -27,7 +27,8 @@ def test_reference_objects_and_gpu_adapter_agree_in_one_process():
     assert "DROP-IN CHECK PASSED" in out.stdout
     assert out.stdout.count(" OK ") >= 12 * 2 + 12 + 6, out.stdout
     assert out.stdout.count("engine chain: decimate8_cen -> FIFO -> work() + DC corr -> channel") == 6
-    assert "one object, K / fcPos changed at run time" in out.stdout
+    assert "RefDec12: one object, K / fcPos changed at run time" in out.stdout
+    assert "DecimatorsFI: one object, K / fcPos changed at run time" in out.stdout
     assert "MISMATCH" not in out.stdout
 
 

@@ -183,6 +183,32 @@ def test_float_decimators_fi_ff_if_random_blocks():
                 L_.ref_fdecim_free(h)
 
 
+def test_float_decimators_variant_switch():
+    """ONE DecimatorsFI / FF / IF object called with changing (K, fcPos): every cascade runs on the object's six filters"""
+    L_ = C.CDLL(REF)
+    vp = C.c_void_p
+    L_.ref_fdecim_new.restype = vp; L_.ref_fdecim_new.argtypes = [C.c_int] * 3
+    L_.ref_fdecim_free.argtypes = [vp]
+    L_.ref_fdecim_process.restype = C.c_int; L_.ref_fdecim_process.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int32, vp]
+    rng = np.random.default_rng(15)
+    for kind, ik, ok, bits in (("fi", 0, 0, 16), ("ff", 0, 1, 16), ("if", 1, 1, 12)):
+        for trial in range(15):
+            h = L_.ref_fdecim_new(ik, ok, bits); o = None
+            for seg in range(7):
+                log2 = int(rng.integers(0, 7)); fc = int(rng.integers(0, 3)) if log2 else 2
+                blk = int(rng.choice([16, 130, 2 * 777, 5000, 40000]))
+                x = rng.uniform(-0.95, 0.95, blk).astype(np.float32) if ik == 0 else rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), blk).astype(np.int16)
+                if o is None:
+                    o = orc.FDecim(kind, log2, fc, bits)
+                else:
+                    o.switch(log2, fc)
+                want = np.zeros(blk + 16, np.int16 if ok == 0 else np.float32)
+                n = L_.ref_fdecim_process(h, log2, fc, x.ctypes.data, blk, want.ctypes.data)
+                got = o.process(x)
+                assert got.size == 2 * n and np.array_equal(got.view(np.uint8), want[: 2 * n].view(np.uint8)), (kind, trial, seg, log2, fc, blk)
+            L_.ref_fdecim_free(h)
+
+
 def test_fftfilt_run_asym_vestigial_sideband():
     """fftfilt(fin, 2048) + create_asym_filter(fopp, fin) + runAsym usb/lsb (fftfilt.cpp:172-225, 363-402; ATV demod) vs the oracle"""
     R = C.CDLL(REF); O = orc.lib(); orc._sig_float(O)
