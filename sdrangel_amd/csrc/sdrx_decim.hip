@@ -808,6 +808,7 @@ int sdrx_decim_stages_create(sdrx_decim_stages_t** out, int device)
     s->device = device;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_rings), SG_DW * 4);
     if (e == hipSuccess) e = hipMemset(s->d_rings, 0, SG_DW * 4);          // freshly constructed filters: all-zero rings
+    if (e == hipSuccess) e = hipDeviceSynchronize();                       // the null-stream memset is not ordered against the handles' non-blocking streams
     if (e != hipSuccess) { if (s->d_rings) (void)hipFree(s->d_rings); delete s; return hip_fail(e, "sdrx_decim_stages_create", __FILE__, __LINE__); }
     *out = s;
     return SDRX_OK;

@@ -286,6 +286,7 @@ int sdrx_fdecim_stages_create(sdrx_fdecim_stages_t** out, int device)
     s->device = device;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_state), (size_t)6 * FD_STATE * sizeof(float));
     if (e == hipSuccess) e = hipMemset(s->d_state, 0, (size_t)6 * FD_STATE * sizeof(float));
+    if (e == hipSuccess) e = hipDeviceSynchronize();       // the null-stream memset is not ordered against the handles' non-blocking streams
     if (e != hipSuccess) { if (s->d_state) (void)hipFree(s->d_state); delete s; return hip_fail(e, "sdrx_fdecim_stages_create", __FILE__, __LINE__); }
     *out = s;
     return SDRX_OK;
