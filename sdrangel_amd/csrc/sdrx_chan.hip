@@ -139,7 +139,8 @@ int subtree_lds(const std::vector<HNode>& trie, int root, int levels, int* n_nod
         if (cur.empty()) break;
     }
     *n_nodes_out = n_entries;
-    return region[0] + region[1] + n_arrays * 16 + n_entries * TK_NODE_DW + n_arrays;      // + one table dword per array
+    // + one table dword per array + the sink descriptors (at most one channel end or node stream per stage, rarely more)
+    return region[0] + region[1] + n_arrays * 16 + n_entries * TK_NODE_DW + n_arrays + 2 * n_entries * TK_SINK_DW + 2;
 }
 
 int height(const std::vector<HNode>& trie, int id)
@@ -212,6 +213,7 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
 
         TkSubtree st; memset(&st, 0, sizeof st);
         st.n_levels = levels;
+        st.sink_base = (int)g->sinks.size();
         st.warm = (int)((46L * ((1L << levels) - 1) + TK_CHUNK - 1) / TK_CHUNK);
         if (st.warm < 1) st.warm = 1;
         g->streams[si].hist_len = (long)(st.warm + 1) * TK_CHUNK;
@@ -345,7 +347,9 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
         }
         st.node_tab = store_base + 16 * st.n_arrays;
         st.arr_tab = st.node_tab + rel_nodes * TK_NODE_DW;
-        st.lds_dwords = st.arr_tab + st.n_arrays;
+        st.n_sinks = (int)g->sinks.size() - st.sink_base;
+        st.sink_tab = (st.arr_tab + st.n_arrays + 1) & ~1;                  // 8-byte aligned: read as uint2
+        st.lds_dwords = st.sink_tab + st.n_sinks * TK_SINK_DW;
         if (st.lds_dwords > 0xffff) { set_error("channel tree does not fit the 16-bit LDS offsets of the array table"); return SDRX_EINVAL; }
         for (int l = 0; l < levels; l++) st.lv[l].in_len = arm_len(l);
         g->max_lds_dw = std::max(g->max_lds_dw, st.lds_dwords);

@@ -66,6 +66,8 @@ struct TkSubtree {
     int n_arrays, array_base;   // all arrays: [root arrays][level-1 arrays][level-2 arrays]...
     int root_arr_cnt;           // the first root_arr_cnt arrays are the root arms
     int lds_dwords;             // two arm regions + history store + node table copy
+    int sink_base, n_sinks;     // this subtree's sinks are one contiguous run of the group's sink table
+    int sink_tab;               // LDS dword offset of the copy of that run (TK_SINK_DW dwords each)
     int node_tab;               // LDS dword offset of the node table copy
     int arr_tab;                // LDS dword offset of the array table copy: off | store << 16, one dword per array
     int rootE_I, rootE_Q, rootO_I, rootO_Q, rootA_I, rootA_Q;   // root arms (-1: none)
@@ -89,12 +91,15 @@ struct TkStream {               // per feed, per input stream of a pass
     long hist_len;              // (warm + 1) * TK_CHUNK
 };
 
+constexpr int TK_SINK_DW = 10;
 struct TkSink {                 // where a node's outputs go in global memory
     uint32_t* ptr;              // element 0 <-> absolute output index `base`
     long base, lo, hi;          // store only absolute output indices in [lo, hi)
     int shift;                  // 0: raw node stream; n > 0: channel end, value / 2^n (toward zero)
     int next;                   // next sink of the same node, -1: end of list
 };
+
+static_assert(sizeof(TkSink) == TK_SINK_DW * 4, "sink table layout");
 
 __device__ __forceinline__ int div_pow2_trunc(int v, int n)
 {
@@ -130,6 +135,10 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
             const TkArray a = arrays[st.array_base + i];
             lds[st.arr_tab + i] = (uint32_t)a.off | ((uint32_t)a.store << 16);
         }
+        // this feed's sink descriptors (pointers, ranges): read by every job of the sink levels -- from LDS, not as a
+        // dependent global load in front of the stores
+        const uint32_t* sk = reinterpret_cast<const uint32_t*>(sinks + st.sink_base);
+        for (int i = tid; i < st.n_sinks * TK_SINK_DW; i += NT) lds[st.sink_tab + i] = sk[i];
     }
 
     uint4 pre[LPT];
@@ -312,7 +321,14 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                     }
                     if (live) {                                                    // channel ends / node streams
                         for (int si = (int)o1.z; si >= 0; ) {
-                            const TkSink sk = sinks[si];
+                            TkSink sk;
+                            {
+                                const uint2* q = reinterpret_cast<const uint2*>(lds + st.sink_tab + (si - st.sink_base) * TK_SINK_DW);
+                                uint2 w[TK_SINK_DW / 2];
+#pragma unroll
+                                for (int u = 0; u < TK_SINK_DW / 2; u++) w[u] = q[u];
+                                __builtin_memcpy(&sk, w, sizeof sk);
+                            }
                             const long rel = abs0 - sk.lo, span = sk.hi - sk.lo;
                             // the sink pointers come out of a table: tell the compiler they are global memory (flat_store otherwise)
                             typedef uint32_t __attribute__((address_space(1))) gu32;
