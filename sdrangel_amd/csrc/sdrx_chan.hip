@@ -48,15 +48,15 @@ static int plan_chain(int32_t in_rate, int32_t req_rate, int32_t req_fc, uint8_t
 namespace {
 
 constexpr int MAX_STAGES = 30;
-constexpr int LDS_BUDGET_DW_DEFAULT = 40 * 1024 / 4 - 64;  // four workgroups per CU (the 64 spare dwords hold the kernel's static copy of TkSubtree)
+constexpr int LDS_BUDGET_DW_DEFAULT = 40 * 1024 / 4;       // four workgroups per CU (the kernel has no static LDS)
 // Wide banks (cfg 4: 256 channels) have a dense tree top whose levels need ~25 KB each; with 40 KB the greedy cut ends up
 // with 1-2 levels per pass and six passes.  64 KB (two workgroups per CU) measured 1.29 vs 1.42 ms per 64 Mi-sample feed
 // for 256 channels, but 0.82 vs 0.71 ms for 128 and 0.62 vs 0.45 ms for 32 -- so only wide banks get it.
 static int lds_budget_dw(size_t n_channels)
 {
     const char* e = getenv("SDRX_CHAN_LDS_KB");
-    if (e && atoi(e) >= 16 && atoi(e) <= 150) return atoi(e) * 1024 / 4 - 64;
-    return n_channels >= 192 ? 64 * 1024 / 4 - 64 : LDS_BUDGET_DW_DEFAULT;
+    if (e && atoi(e) >= 16 && atoi(e) <= 150) return atoi(e) * 1024 / 4;
+    return n_channels >= 192 ? 64 * 1024 / 4 : LDS_BUDGET_DW_DEFAULT;
 }
 constexpr int LDS_HARD_DW = 150 * 1024 / 4;
 // levels per pass: 6 = one warm-up chunk per segment.  Deeper passes (experiment, DESIGN 4.3: fewer node-stream bytes
@@ -121,7 +121,7 @@ int arm_len(int rel_depth) { return HIST / 2 + (TK_CHUNK >> (rel_depth + 2)); } 
 // (a lower/upper sibling pair shares one entry)
 int subtree_lds(const std::vector<HNode>& trie, int root, int levels, int* n_nodes_out)
 {
-    int region[2] = { 0, 0 }, n_arrays = 0, n_entries = 0;
+    int region[2] = { 0, 0 }, n_arrays = 0, n_entries = 0, n_sinks = 0;
     std::vector<int> cur{ root };
     for (int rel = 0; rel < levels; rel++) {
         std::vector<int> nxt;
@@ -132,15 +132,21 @@ int subtree_lds(const std::vector<HNode>& trie, int root, int levels, int* n_nod
             const int na = 2 + (c ? 2 : 0) + (lu ? 2 : 0);
             level_dw += arm_len(rel) * na; n_arrays += na;
             n_entries += (c ? 1 : 0) + (lu ? 1 : 0);
-            for (int m = 0; m < 3; m++) if (trie[id].child[m] >= 0) nxt.push_back(trie[id].child[m]);
+            for (int m = 0; m < 3; m++) if (trie[id].child[m] >= 0) {
+                const int kid = trie[id].child[m];
+                nxt.push_back(kid);
+                // sinks of the stage: every channel that ends there, plus a node stream where the tree goes on below the pass
+                n_sinks += (int)trie[kid].ends.size();
+                if (rel + 1 == levels && (trie[kid].child[0] >= 0 || trie[kid].child[1] >= 0 || trie[kid].child[2] >= 0)) n_sinks++;
+            }
         }
         region[rel & 1] = std::max(region[rel & 1], level_dw);
         cur.swap(nxt);
         if (cur.empty()) break;
     }
     *n_nodes_out = n_entries;
-    // + one table dword per array + the sink descriptors (at most one channel end or node stream per stage, rarely more)
-    return region[0] + region[1] + n_arrays * 16 + n_entries * TK_NODE_DW + n_arrays + 2 * n_entries * TK_SINK_DW + 2;
+    // + one table dword per array (+ 1 for the 8-byte alignment of what follows) + the sink descriptors
+    return region[0] + region[1] + n_arrays * 16 + n_entries * TK_NODE_DW + n_arrays + 1 + n_sinks * TK_SINK_DW;
 }
 
 int height(const std::vector<HNode>& trie, int id)
@@ -506,14 +512,14 @@ static int feed_group(sdrx_chan_bank* b, Group* g, const uint32_t* d_in, int64_t
         if (si.kind == 0) {
             Channel& ch = b->ch[si.ch];
             t.lo = T0 >> si.depth; t.hi = T1 >> si.depth;
-            t.base = t.lo - ch.avail;
-            t.ptr = static_cast<uint32_t*>(ch.out.p);
+            // element 0 of the queue's free space <-> absolute index lo; the address of index 0 is only ever used with an offset back into the buffer
+            t.ptr0 = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(ch.out.p) - (uintptr_t)(4 * (t.lo - ch.avail)));
             t.shift = si.depth;
             if (ch.group != g->index) t.hi = t.lo;         // reconfigured away: still evaluated, not stored
         } else {
             Stream& s = g->streams[si.stream];
-            t.lo = T0 >> s.depth; t.hi = T1 >> s.depth; t.base = t.lo;
-            t.ptr = static_cast<uint32_t*>(s.mid.p);
+            t.lo = T0 >> s.depth; t.hi = T1 >> s.depth;
+            t.ptr0 = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(s.mid.p) - (uintptr_t)(4 * t.lo));
         }
     }
     // chunks per segment, per pass: ~4 workgroups per CU overall, warm-up overhead <= 1/cps

@@ -5,7 +5,7 @@
 //
 // The N channels' stage strings form a trie; every distinct prefix (= node) is ONE order-48
 // half-band stage evaluated ONCE.  The host planner (sdrx_chan.hip) cuts the trie into passes of
-// at most 6 levels by default (TK_MAX_LEVELS is the structural limit): a pass reads a stream (the raw
+// at most 4 levels by default (TK_MAX_LEVELS is the structural limit): a pass reads a stream (the raw
 // input, or a node stream a previous pass wrote to global memory), walks it in chunks of 4096 samples
 // with all stage histories carried in LDS, and writes channel outputs and/or deeper node streams.
 // `warm` warm-up chunks (warm * 4096 >= 46*(2^levels - 1): one chunk up to 6 levels) in front of every
@@ -26,7 +26,8 @@ namespace sdrx {
 constexpr int TK_CHUNK = 4096;
 constexpr int TK_THREADS = 256;
 constexpr int TK_MAX_LEVELS = 10;
-constexpr int TK_DEFAULT_LEVELS = 6;         // what the planner uses unless told otherwise (one warm-up chunk)
+constexpr int TK_DEFAULT_LEVELS = 4;         // what the planner uses unless told otherwise: measured best for 32, 128 and 256 channels
+                                             // (profiles/r02_tree_plan_sweep.txt); up to 6 levels need one warm-up chunk
 constexpr int TK_HIST = 2 * TK_CHUNK;        // samples of stream history kept between feeds: (warm + 1) chunks, this for warm = 1
 
 // One table entry = one half-band stage, or a FUSED lower/upper sibling pair: the lower- and the upper-half
@@ -91,10 +92,10 @@ struct TkStream {               // per feed, per input stream of a pass
     long hist_len;              // (warm + 1) * TK_CHUNK
 };
 
-constexpr int TK_SINK_DW = 10;
+constexpr int TK_SINK_DW = 8;
 struct TkSink {                 // where a node's outputs go in global memory
-    uint32_t* ptr;              // element 0 <-> absolute output index `base`
-    long base, lo, hi;          // store only absolute output indices in [lo, hi)
+    uint32_t* ptr0;             // element for absolute output index 0 (= buffer - base: never dereferenced outside [lo, hi))
+    long lo, hi;                // store only absolute output indices in [lo, hi)
     int shift;                  // 0: raw node stream; n > 0: channel end, value / 2^n (toward zero)
     int next;                   // next sink of the same node, -1: end of list
 };
@@ -332,7 +333,7 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                             const long rel = abs0 - sk.lo, span = sk.hi - sk.lo;
                             // the sink pointers come out of a table: tell the compiler they are global memory (flat_store otherwise)
                             typedef uint32_t __attribute__((address_space(1))) gu32;
-                            gu32* dst = (gu32*)(sk.ptr + (abs0 - sk.base));
+                            gu32* dst = (gu32*)(sk.ptr0 + abs0);
                             if (rel >= 0 && rel + R <= span) {                     // whole job in range: no per-sample guards
 #pragma unroll
                                 for (int r = 0; r < R; r++)

@@ -22,6 +22,15 @@ def fold(pattern):
     return acc
 
 
+def per_feed(f, w, k):
+    """launches of kernel k per bank feed = its launches / launches of tree_hist_kernel (one per feed)"""
+    if not k.startswith("tree_kernel"):
+        return 1
+    n_k = max(len(f.get((k, "FETCH_SIZE"), [])), len(w.get((k, "WRITE_SIZE"), [])))
+    n_h = max(len(f.get(("tree_hist_kernel", "FETCH_SIZE"), [])), len(w.get(("tree_hist_kernel", "WRITE_SIZE"), [])))
+    return n_k / n_h if n_h else 1
+
+
 out = {"note": "bytes per launch; read = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB; separate --pmc passes", "kernels": []}
 for wl, batch, alg in (("decim64", b_decim, 4.0625), ("chan32", b_chan, 4.125), ("fi64", 536870912, 8.0625)):
     f = fold(f"pmc_fetch_{wl}"); w = fold(f"pmc_write_{wl}")
@@ -36,8 +45,8 @@ for wl, batch, alg in (("decim64", b_decim, 4.0625), ("chan32", b_chan, 4.125), 
                                "fetch_size_kib_raw": sum(fv) / len(fv) if fv else None,
                                "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                                "hbm_bytes_per_launch": (rd or 0) + (wr or 0),
-                               # a bank feed = `passes` tree_kernel launches (cfg 3: two); the decimator is one launch per step
-                               "hbm_bytes_per_step": ((rd or 0) + (wr or 0)) * (2 if (wl == "chan32" and k.startswith("tree_kernel")) else 1),
+                               # a bank feed = one tree_kernel launch per pass and ONE tree_hist_kernel launch: launches per feed from that
+                               "hbm_bytes_per_step": ((rd or 0) + (wr or 0)) * (per_feed(f, w, k) if wl == "chan32" else 1),
                                "algorithmic_bytes_per_launch": alg * batch})
 json.dump(out, open(os.path.join("profiles", f"{tag}_traffic.json"), "w"), indent=1)
 for e in out["kernels"]:
