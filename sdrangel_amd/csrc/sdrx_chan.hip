@@ -81,6 +81,7 @@ struct Channel {
     uint8_t modes[32] = { 0 };
     int group = -1;               // -1: pass-through (0 stages) or dead
     bool passthrough = false;
+    bool dead = false;            // removed: the index stays reserved, nothing is produced any more
     DevBuf out;                   // device queue of packed Samples
     int64_t avail = 0;            // complex samples queued
     int64_t last_off = 0, last_n = 0;
@@ -662,7 +663,7 @@ int sdrx_chan_bank_reconfigure(sdrx_chan_bank_t* b, int32_t c, int32_t req_rate,
     // the old chain keeps being evaluated inside its group (its prefixes are shared) but stops
     // storing; the new chain starts from zero history in a group of its own
     // (freeFilterChain + createFilterChain, downchannelizer.cpp:167-171)
-    ch.group = -1;
+    ch.group = -1; ch.dead = false;                        // (a removed channel comes back with the new configuration)
     configure_channel(b, c, req_rate, req_fc);
     // a group whose last live channel this was (typically the single-channel group of an earlier reconfigure) goes away;
     // dead chains inside a group that still serves others keep being evaluated (shared prefixes) until the next reset
@@ -692,7 +693,7 @@ int sdrx_chan_bank_remove_channel(sdrx_chan_bank_t* b, int32_t c)
     SDRX_HIP(hipSetDevice(b->device));
     // the index stays reserved (other channels keep theirs); the chain stops producing and its queue is dropped
     Channel& ch = b->ch[(size_t)c];
-    ch.group = -1; ch.passthrough = false; ch.n = 0; ch.out_rate = 0; ch.ofs = 0;
+    ch.group = -1; ch.passthrough = false; ch.dead = true; ch.n = 0; ch.out_rate = 0; ch.ofs = 0;
     ch.avail = 0; ch.last_off = 0; ch.last_n = 0;
     return retire_dead_groups(b);
 }
@@ -709,7 +710,7 @@ int sdrx_chan_bank_reset(sdrx_chan_bank_t* b)
     std::vector<int> all;
     for (size_t c = 0; c < b->ch.size(); c++) {
         b->ch[c].avail = 0; b->ch[c].last_n = 0; b->ch[c].group = -1;
-        if (!b->ch[c].passthrough) all.push_back((int)c);
+        if (!b->ch[c].passthrough && !b->ch[c].dead) all.push_back((int)c);
     }
     return new_group(b, all);
 }
