@@ -105,7 +105,7 @@ void EventTimer::release()
 
 extern "C" {
 
-const char* sdrx_version(void) { return "sdrx 0.1 (gfx950)"; }
+const char* sdrx_version(void) { return "sdrx 0.2 (gfx950)"; }
 const char* sdrx_last_error(void) { return sdrx::g_last_error.c_str(); }
 
 int sdrx_device_count(void)
