@@ -1,4 +1,5 @@
-// FAST path of the Decimators chain: one WAVE = one private pipeline, no workgroup barrier.
+// FAST path of the Decimators chain: one WAVE = one private pipeline, no workgroup barrier (NW = 1, long launches; the
+// NW = 4 flavour for short launches is described at the kernel).
 //
 // Each 64-lane workgroup (a single wavefront) owns `spw` consecutive sub-chunks of 1024 input
 // samples and walks them in order through all L half-band stages, every stage's history carried
@@ -186,18 +187,22 @@ __device__ __forceinline__ void stage_i32_split(const int* __restrict__ oI, cons
 
 // LDS layout of one wave (dwords)
 __host__ __device__ constexpr bool df_in16(int s) { return s <= 3; }          // stage s reads packed int16 arms
-__host__ __device__ constexpr int df_arr(int s)
+__host__ __device__ constexpr int df_arr(int s, int S = DF_SUB)
 {
     // int32 (tail) arrays are only ever touched with 4-byte accesses by lanes that alternate between the I and
     // the Q array: an ODD array pitch puts the two on opposite bank parities (SQ_LDS_BANK_CONFLICT was 24 % of
     // the LDS cycles with the natural 96/64/48-dword pitches, all multiples of 16 banks)
-    return df_in16(s) ? (HIST / 2 + (DF_SUB >> (s + 1))) : (HIST + (DF_SUB >> s) + 1);
+    return df_in16(s) ? (HIST / 2 + (S >> (s + 1))) : (HIST + (S >> s) + 1);
 }
-__host__ __device__ constexpr int df_off(int s) { int o = 0; for (int u = 1; u < s; u++) o += 4 * df_arr(u); return o; }
-__host__ __device__ constexpr int df_lds_dwords(int L) { return df_off(L + 1); }
+__host__ __device__ constexpr int df_off(int s, int S = DF_SUB) { int o = 0; for (int u = 1; u < s; u++) o += 4 * df_arr(u, S); return o; }
+__host__ __device__ constexpr int df_lds_dwords(int L, int S = DF_SUB) { return df_off(L + 1, S); }
 
-template<int L, int FC, int PRE, bool U8>
-__global__ __launch_bounds__(64)
+// NW = waves per workgroup.  NW = 1: the wave-private pipeline described at the top (sub-chunks of 1024 samples, 4 warm-up
+// sub-chunks per segment).  NW = 4: the same lane work on sub-chunks of 4096 samples with a real barrier behind every stage and ONE
+// warm-up sub-chunk per segment -- a quarter of the warm-up per wave, for calls too short to give every SIMD several
+// single-wave segments of a useful length (the host picks, sdrx_decim.hip).
+template<int L, int FC, int PRE, bool U8, int NW>
+__global__ __launch_bounds__(64 * NW)
 void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
 {
     typedef typename Quad<U8>::T QT;
@@ -208,15 +213,16 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
     uint32_t* __restrict__ ovf_flags = job.flags;          // one per DF_CHUNK-sample chunk of this call
     const long n_in = job.n_in;
     const int n_sub = job.n_units;
-    constexpr int S = DF_SUB, LPT = S / 4 / 64;            // 4 uint4 per lane per sub-chunk
-    __shared__ __attribute__((aligned(16))) uint32_t lds[df_lds_dwords(L)];
+    constexpr int S = DF_SUB * NW, NT = 64 * NW, WARM = DF_WARM / NW, LPT = S / 4 / NT;   // 4 uint4 per lane per sub-chunk
+    static_assert(NW == 1 || NW == 2 || NW == 4, "warm-up = 4096 samples = a whole number of sub-chunks (2 measured: never the best)");
+    __shared__ __attribute__((aligned(16))) uint32_t lds[df_lds_dwords(L, S)];
     const int lane = threadIdx.x;
     const long first = (long)blockIdx.x * spw;
     if (first >= n_sub) return;
     long last = first + spw; if (last > n_sub) last = n_sub;
     const long n_in4 = n_in >> 2, n_out = n_in >> L;
 
-    for (int i = lane; i < df_lds_dwords(L); i += 64) lds[i] = 0;
+    for (int i = lane; i < df_lds_dwords(L, S); i += NT) lds[i] = 0;
 
     QT pre[LPT];
     // A sub-chunk is either wholly history (sub < 0) or wholly input: the source is chosen with a wave-uniform (scalar)
@@ -224,26 +230,26 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
     auto fetch = [&](long sub) {
         const QT* __restrict__ src;
         long left;
-        if (sub < 0) { src = hist + (sub + DF_WARM) * (S / 4); left = S / 4; }
+        if (sub < 0) { src = hist + (sub + WARM) * (S / 4); left = S / 4; }
         else { src = in + sub * (S / 4); left = n_in4 - sub * (S / 4); }
         const int lim = left > S / 4 ? S / 4 : (int)left;
 #pragma unroll
         for (int j = 0; j < LPT; j++) {
-            const int q = j * 64 + lane;
+            const int q = j * NT + lane;
             pre[j] = q < lim ? src[q] : Quad<U8>::zero();
         }
     };
-    fetch(first - DF_WARM);
+    fetch(first - WARM);
     bool bad = false;
     uint32_t ovf_or = 0;                                       // OR of (y + 0x8000) over every int16-stored output so far
     __syncthreads();
 
-    for (long sub = first - DF_WARM; sub < last; ++sub) {
+    for (long sub = first - WARM; sub < last; ++sub) {
         {
-            uint32_t* oI = lds + df_off(1), *oQ = oI + df_arr(1), *eI = oQ + df_arr(1), *eQ = eI + df_arr(1);
+            uint32_t* oI = lds + df_off(1, S), *oQ = oI + df_arr(1, S), *eI = oQ + df_arr(1, S), *eQ = eI + df_arr(1, S);
 #pragma unroll
             for (int j = 0; j < LPT; j++) {
-                const int q = HIST / 2 + j * 64 + lane;
+                const int q = HIST / 2 + j * NT + lane;
                 Quad<U8>::split(pre[j], in_shift, eI[q], eQ[q], oI[q], oQ[q]);
             }
         }
@@ -255,8 +261,8 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
             constexpr int s = decltype(sc)::value;
             constexpr int MODE = dc_mode(L, FC, s);
             constexpr int NOUT = S >> s;
-            const uint32_t* iI = lds + df_off(s), *iQ = iI + df_arr(s), *jI = iQ + df_arr(s), *jQ = jI + df_arr(s);   // oI,oQ,eI,eQ
-            uint32_t* nI = lds + df_off(s + 1);                // next stage: oI, oQ, eI, eQ
+            const uint32_t* iI = lds + df_off(s, S), *iQ = iI + df_arr(s, S), *jI = iQ + df_arr(s, S), *jQ = jI + df_arr(s, S);   // oI,oQ,eI,eQ
+            uint32_t* nI = lds + df_off(s + 1, S);                // next stage: oI, oQ, eI, eQ
             if constexpr (s <= 3) {
                 constexpr int R = 16 >> s;                     // 8, 4, 2
                 int yI[R], yQ[R];
@@ -268,10 +274,10 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
 #pragma unroll
                         for (int r = 0; r < R; r++)
                             ovf_or |= ((uint32_t)yI[r] + 0x8000u) | ((uint32_t)yQ[r] + 0x8000u);
-                        put_pk16<R>(nI, nI + df_arr(s + 1), nI + 2 * df_arr(s + 1), nI + 3 * df_arr(s + 1), lane, yI, yQ);
+                        put_pk16<R>(nI, nI + df_arr(s + 1, S), nI + 2 * df_arr(s + 1, S), nI + 3 * df_arr(s + 1, S), lane, yI, yQ);
                     } else {
                         int* d = reinterpret_cast<int*>(nI);
-                        put_i32<R>(d, d + df_arr(s + 1), d + 2 * df_arr(s + 1), d + 3 * df_arr(s + 1), lane, yI, yQ);
+                        put_i32<R>(d, d + df_arr(s + 1, S), d + 2 * df_arr(s + 1, S), d + 3 * df_arr(s + 1, S), lane, yI, yQ);
                     }
                 } else if (live) {
                     const long base = sub * NOUT + (long)R * lane;
@@ -287,8 +293,8 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
                                                    lane, y, p, comp);
                 if constexpr (s < L) {
                     int* d = reinterpret_cast<int*>(nI);       // oI, oQ, eI, eQ of the next stage
-                    int* od = d + (comp ? df_arr(s + 1) : 0);
-                    int* ed = d + (comp ? 3 * df_arr(s + 1) : 2 * df_arr(s + 1));
+                    int* od = d + (comp ? df_arr(s + 1, S) : 0);
+                    int* ed = d + (comp ? 3 * df_arr(s + 1, S) : 2 * df_arr(s + 1, S));
                     ed[HIST + p] = y[0]; od[HIST + p] = y[1];
                 } else {
                     // partner component sits SPLIT lanes up; lanes with comp == 0 and slice 0 store
@@ -308,7 +314,8 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
         // overflow bookkeeping (wave-uniform): any int16-stored output out of range so far?
         if constexpr (L >= 2) {
             const bool mine = (ovf_or >> 16) != 0;
-            if (!bad && __any(mine)) bad = true;
+            if constexpr (NW == 1) { if (!bad && __any(mine)) bad = true; }
+            else { if (__syncthreads_or(mine ? 1 : 0)) bad = true; }
         }
         if (live && lane == 0 && ((sub + 1) % (DF_CHUNK / S) == 0 || sub + 1 == last))
             ovf_flags[sub / (DF_CHUNK / S)] = bad ? 1u : 0u;
@@ -319,26 +326,26 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
         static_for<1, L + 1>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             constexpr int HD = df_in16(s) ? HIST / 2 : HIST;
-            constexpr int ND = df_in16(s) ? (DF_SUB >> (s + 1)) : (DF_SUB >> s);      // payload dwords per array
-            constexpr int TOT = 4 * HD, PER = TOT / 64;
-            static_assert(TOT % 64 == 0, "four arrays x 16 or 32 history dwords: a whole number of wave-wide accesses, no lane test");
-            const uint32_t* a = lds + df_off(s);
+            constexpr int ND = df_in16(s) ? (S >> (s + 1)) : (S >> s);                // payload dwords per array
+            constexpr int TOT = 4 * HD, PER = (TOT + NT - 1) / NT;
+            static_assert(TOT % 64 == 0, "four arrays x 16 or 32 history dwords: a whole number of wave-wide accesses");
+            const uint32_t* a = lds + df_off(s, S);
 #pragma unroll
             for (int q = 0; q < PER; q++) {
-                const int i = q * 64 + lane;
-                keep[s - 1][q] = a[(i / HD) * df_arr(s) + ND + (i % HD)];
+                const int i = q * NT + lane;
+                if (NW == 1 || i < TOT) keep[s - 1][q] = a[(i / HD) * df_arr(s, S) + ND + (i % HD)];
             }
         });
         __syncthreads();
         static_for<1, L + 1>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             constexpr int HD = df_in16(s) ? HIST / 2 : HIST;
-            constexpr int TOT = 4 * HD, PER = TOT / 64;
-            uint32_t* a = lds + df_off(s);
+            constexpr int TOT = 4 * HD, PER = (TOT + NT - 1) / NT;
+            uint32_t* a = lds + df_off(s, S);
 #pragma unroll
             for (int q = 0; q < PER; q++) {
-                const int i = q * 64 + lane;
-                a[(i / HD) * df_arr(s) + (i % HD)] = keep[s - 1][q];
+                const int i = q * NT + lane;
+                if (NW == 1 || i < TOT) a[(i / HD) * df_arr(s, S) + (i % HD)] = keep[s - 1][q];
             }
         });
         __syncthreads();

@@ -123,15 +123,17 @@ __global__ void decim_serial_kernel(const SerialJob jb)
 typedef void (*chain_fn)(const DecimJobs, int, int, int);
 typedef void (*fast_fn)(const DecimJobs, int, int, int);
 
-struct ChainEntry { chain_fn fn; fast_fn fast; const char* name; const char* fast_name; int lds; int fast_lds; };
+struct ChainEntry { chain_fn fn; fast_fn fast; const char* name; const char* fast_name; int lds; int fast_lds; fast_fn fast4; const char* fast4_name; int fast4_lds; };
 
 template<int L, int FC, int PRE, bool U8> static ChainEntry entry()
 {
-    static char name[64], fname[64];
+    static char name[64], fname[64], f4name[64];
     snprintf(name, sizeof name, "decim_chain_kernel<%d,%d,%d,%d>", L, FC, PRE, (int)U8);
-    snprintf(fname, sizeof fname, "decim_fast_kernel<%d,%d,%d,%d>", L, FC, PRE, (int)U8);
-    return ChainEntry{ &decim_chain_kernel<L, FC, PRE, U8>, &decim_fast_kernel<L, FC, PRE, U8>, name, fname,
-                       dc_lds_dwords(L) * 4, df_lds_dwords(L) * 4 };
+    snprintf(fname, sizeof fname, "decim_fast_kernel<%d,%d,%d,%d,1>", L, FC, PRE, (int)U8);
+    snprintf(f4name, sizeof f4name, "decim_fast_kernel<%d,%d,%d,%d,4>", L, FC, PRE, (int)U8);
+    return ChainEntry{ &decim_chain_kernel<L, FC, PRE, U8>, &decim_fast_kernel<L, FC, PRE, U8, 1>, name, fname,
+                       dc_lds_dwords(L) * 4, df_lds_dwords(L) * 4,
+                       &decim_fast_kernel<L, FC, PRE, U8, 4>, f4name, df_lds_dwords(L, 4 * DF_SUB) * 4 };
 }
 
 // decimation_shifts<16,InputBits> (decimators.h:25-185)
@@ -194,7 +196,7 @@ struct sdrx_decim {
     bool rings_live = false;
     long since_load = 0;
     int path = 0;                 // 0 auto (FAST + flagged EXACT), 1 exact only, 2 fast only (debug: no fallback)
-    ChainEntry k{ nullptr, nullptr, "", "", 0, 0 };
+    ChainEntry k{ nullptr, nullptr, "", "", 0, 0, nullptr, "", 0 };
     char last_name[96] = "";
     int last_grid = 0, last_block = 0, last_lds = 0;
     EventTimer timer;
@@ -284,6 +286,19 @@ static int run_transition(sdrx_decim* x, hipStream_t stream, const void* d_iq, l
     return SDRX_OK;
 }
 
+// Waves per workgroup of the FAST kernel for a launch of `total_in` samples (all streams of the batch).  A single-wave
+// segment carries 4096 samples of warm-up; a call of a few M samples cannot give every SIMD several of them at a useful
+// length.  Four waves on one segment share ONE warm-up chunk and a quarter of the serial path, at the price of a barrier
+// behind every stage: 1 Mi samples 67 vs 36 GS/s, 4 Mi 172 vs 128, 10 M (BASELINE cfg 2's own size) 207 vs 177, 16 Mi 252 vs
+// 257, 64 Mi 344 vs 392, 1 Gi 452 vs 553 (profiles/r02_decim_nw_sweep.txt).
+static int fast_nw(const sdrx_decim* h, long total_in)
+{
+    const char* env = getenv("SDRX_DECIM_NW");
+    if (env && (atoi(env) == 1 || atoi(env) == 4)) return atoi(env);
+    (void)h;
+    return total_in <= 12L * 1024 * 1024 ? 4 : 1;
+}
+
 // One launch (per kernel) for n <= DJ_MAX streams of one configuration: hs[i] consumes n_cplx[i] whole-group samples
 // at d_iq[i] into d_out[i].  Everything is queued on hs[0]'s stream; timing and last_launch are kept on hs[0].
 static int launch_batch(sdrx_decim* const* hs, int n, const void* const* d_iq_in, const long* n_cplx_in, int16_t* const* d_out_in)
@@ -332,37 +347,60 @@ static int launch_batch(sdrx_decim* const* hs, int n, const void* const* d_iq_in
     bool have_flags = false;
     int trc = h->timer.begin(h->stream); if (trc) return trc;
     if (h->path != 1) {
-        // FAST: one wave per segment of `spw` sub-chunks (multiple of 4 = one flag chunk), 4 warm-up
+        // FAST: one wave per segment of `spw` sub-chunks (multiple of 4 = one flag chunk), 4 warm-up sub-chunks -- or, for
+        // calls too short for that (fast_nw), four waves per segment on sub-chunks of 4096 samples with one warm-up sub-chunk
+        long total_in = 0;
+        for (int i = 0; i < n; i++) total_in += jobs.j[i].n_in;
+        const int nw = fast_nw(h, total_in);
+        const long sub_len = (long)DF_SUB * nw;
         long tot_sub = 0, max_sub = 0;
         for (int i = 0; i < n; i++) {
             const long chunks = (jobs.j[i].n_in + DC_CHUNK - 1) / DC_CHUNK;
             trc = hs[i]->d_flags.reserve((size_t)(chunks > 0 ? chunks : 1) * 4); if (trc) return trc;
             jobs.j[i].flags = static_cast<uint32_t*>(hs[i]->d_flags.p);
-            const long ns = (jobs.j[i].n_in + DF_SUB - 1) / DF_SUB;
+            const long ns = (jobs.j[i].n_in + sub_len - 1) / sub_len;
             jobs.j[i].n_units = (int)ns; tot_sub += ns; if (ns > max_sub) max_sub = ns;
         }
         have_flags = true;
-        // segment length: 32 sub-chunks (12.5 % warm-up) measured best once that still gives >= 8 waves
-        // per CU (sweep in profiles/r01_decim_sweep.txt); shorter inputs trade warm-up against fill.  A batch is
-        // sized by the sub-chunks of ALL its streams: that is what fills the chip.
-        const long slots = (long)h->cus * 8;
-        long spw = 32; double best = 1e300;
-        const char* env = getenv("SDRX_DECIM_SPW");
-        if (env && atoi(env) >= 4) spw = (atoi(env) / 4) * 4;
-        else if (tot_sub >= 8 * 32 * slots) spw = 64;          // long launches: halve the warm-up share (512 Mi samples: 429 vs 418 GS/s, 1 Gi: 494 vs 471)
-        else if (tot_sub < 32 * slots) for (long c = 4; c <= 32; c += 4) {
-            long segs = 0;
-            for (int i = 0; i < n; i++) segs += (jobs.j[i].n_units + c - 1) / c;
-            const long rounds = (segs + slots - 1) / slots;
-            const double cost = (double)(c + DF_WARM) * (double)rounds;
-            if (cost < best - 1e-9) { best = cost; spw = c; }
+        long spw;
+        if (nw == 1) {
+            // segment length: 32 sub-chunks (12.5 % warm-up) measured best once that still gives >= 8 waves
+            // per CU (sweep in profiles/r01_decim_sweep.txt); shorter inputs trade warm-up against fill.  A batch is
+            // sized by the sub-chunks of ALL its streams: that is what fills the chip.
+            const long slots = (long)h->cus * 8;
+            spw = 32; double best = 1e300;
+            const char* env = getenv("SDRX_DECIM_SPW");
+            if (env && atoi(env) >= 4) spw = (atoi(env) / 4) * 4;
+            else if (tot_sub >= 8 * 32 * slots) spw = 64;          // long launches: halve the warm-up share (512 Mi samples: 429 vs 418 GS/s, 1 Gi: 494 vs 471)
+            else if (tot_sub < 32 * slots) for (long c = 4; c <= 32; c += 4) {
+                long segs = 0;
+                for (int i = 0; i < n; i++) segs += (jobs.j[i].n_units + c - 1) / c;
+                const long rounds = (segs + slots - 1) / slots;
+                const double cost = (double)(c + DF_WARM) * (double)rounds;
+                if (cost < best - 1e-9) { best = cost; spw = c; }
+            }
+            if (spw > max_sub) spw = ((max_sub + 3) / 4) * 4;
+        } else {
+            // 4-wave workgroups: 3 per CU (45 KB of LDS each), one warm-up sub-chunk per segment
+            const long slots = (long)h->cus * 3;
+            const int warm = DF_WARM / nw;
+            spw = 8; double best = 1e300;
+            const char* env = getenv("SDRX_DECIM_SPW");
+            if (env && atoi(env) >= 1) spw = atoi(env);
+            else for (long c = 1; c <= 32; c++) {
+                long segs = 0;
+                for (int i = 0; i < n; i++) segs += (jobs.j[i].n_units + c - 1) / c;
+                const long rounds = (segs + slots - 1) / slots;
+                const double cost = (double)(c + warm) * (double)rounds;
+                if (cost < best - 1e-9) { best = cost; spw = c; }
+            }
+            if (spw > max_sub) spw = max_sub;
         }
-        if (spw > max_sub) spw = ((max_sub + 3) / 4) * 4;
         const long segs = (max_sub + spw - 1) / spw;
-        hipLaunchKernelGGL(h->k.fast, dim3((unsigned)segs, (unsigned)n), dim3(64), 0, h->stream, jobs, (int)spw, h->post, h->in_shift);
+        hipLaunchKernelGGL(nw == 1 ? h->k.fast : h->k.fast4, dim3((unsigned)segs, (unsigned)n), dim3(64 * nw), 0, h->stream, jobs, (int)spw, h->post, h->in_shift);
         SDRX_HIP(hipGetLastError());
-        snprintf(h->last_name, sizeof h->last_name, "%s", h->k.fast_name);
-        h->last_grid = (int)(segs * n); h->last_block = 64; h->last_lds = h->k.fast_lds;
+        snprintf(h->last_name, sizeof h->last_name, "%s", nw == 1 ? h->k.fast_name : h->k.fast4_name);
+        h->last_grid = (int)(segs * n); h->last_block = 64 * nw; h->last_lds = nw == 1 ? h->k.fast_lds : h->k.fast4_lds;
     }
     if (h->path != 2) {
         for (int i = 0; i < n; i++) jobs.j[i].n_units = (int)((jobs.j[i].n_in + DC_CHUNK - 1) / DC_CHUNK);

@@ -7,6 +7,13 @@ from tests import oracle_py as orc
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=["1", "4"], autouse=True)
+def _fast_flavour(request, monkeypatch):
+    """both flavours of the FAST kernel: single-wave workgroups (long launches) and four-wave workgroups (short ones);
+    the library picks by launch size, the tests pin each in turn"""
+    monkeypatch.setenv("SDRX_DECIM_NW", request.param)
+
 BITS = (12, 8, 16)
 
 

@@ -9,6 +9,13 @@ import sdrangel_amd as sa
 from tests import oracle_py as orc
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["1", "4"], autouse=True)
+def _fast_flavour(request, monkeypatch):
+    """both flavours of the FAST kernel: single-wave workgroups (long launches) and four-wave workgroups (short ones);
+    the library picks by launch size, the tests pin each in turn"""
+    monkeypatch.setenv("SDRX_DECIM_NW", request.param)
 import os
 N_EX = int(os.environ.get("SDRX_HYP_EXAMPLES", "30"))           # a soak run sets this to a few hundred and drops derandomize
 SET = dict(max_examples=N_EX, deadline=None, derandomize=N_EX <= 30, database=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
