@@ -527,7 +527,9 @@ static int feed_group(sdrx_chan_bank* b, Group* g, const uint32_t* d_in, int64_t
     for (size_t p = 0; p < g->passes.size(); p++) {
         long total_chunks = 0;
         for (int si : g->passes[p]) total_chunks += std::max(0L, hs[si].c_last - hs[si].c_first + 1);
-        long cps = total_chunks / ((long)b->cus * 4);
+        // one round of workgroups (4 per CU) where the feed allows it: rounding DOWN here leaves a few segments for a second,
+        // nearly empty round (61.44 M samples: 1072 workgroups for 1024 slots)
+        long cps = (total_chunks + (long)b->cus * 4 - 1) / ((long)b->cus * 4);
         const char* env = getenv("SDRX_CHAN_CPS");
         if (env && atoi(env) > 0) cps = atoi(env);
         cps = std::max(1L, std::min(cps, 256L));
