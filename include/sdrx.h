@@ -169,6 +169,12 @@ int sdrx_chan_bank_add_channel(sdrx_chan_bank_t* h, int32_t req_rate, int32_t re
 int sdrx_chan_bank_remove_channel(sdrx_chan_bank_t* h, int32_t ch);
 /* number of independently planned stage tries the bank currently evaluates per feed (1 after create / reset; a
  * reconfigured or added channel runs in a trie of its own, and tries without a live channel are retired) */
+/* checkpoint of the bank's filter state: every stream's history and sample count (the reference's per-stage rings are a
+ * pure function of them); queued, unread output is not part of it.  A state fits only a bank with the same channels
+ * configured in the same order; set_state checks the shape, drops what is queued and continues the saved timeline. */
+int64_t sdrx_chan_bank_state_bytes(const sdrx_chan_bank_t* b);
+int sdrx_chan_bank_get_state(sdrx_chan_bank_t* b, void* host_buf);
+int sdrx_chan_bank_set_state(sdrx_chan_bank_t* b, const void* host_buf);
 int32_t sdrx_chan_bank_group_count(const sdrx_chan_bank_t* h);
 int sdrx_chan_bank_reset(sdrx_chan_bank_t* h);
 
@@ -407,6 +413,10 @@ int sdrx_fdecim_sync(sdrx_fdecim_t* h);
 int sdrx_fdecim_set_stream(sdrx_fdecim_t* h, void* hip_stream);
 /* input elements per loop iteration of the reference method (its `pos +=` stride) */
 int32_t sdrx_fdecim_group(int log2_decim, int fcpos);
+/* checkpoint of the carried state (the cascade's filter rings) */
+int64_t sdrx_fdecim_state_bytes(const sdrx_fdecim_t* h);
+int sdrx_fdecim_get_state(sdrx_fdecim_t* h, void* host_buf);
+int sdrx_fdecim_set_state(sdrx_fdecim_t* h, const void* host_buf);
 /* the six IntHalfbandFilterEOF members that all decimateK_x of one DecimatorsFI / FF / IF object share (cascade stage s is
  * member s in every variant): same protocol as sdrx_decim_save_stages / _load_stages.  The float handles carry their filters'
  * rings explicitly, so both calls are plain device copies. */

@@ -153,6 +153,12 @@ def lib() -> C.CDLL:
         "sdrx_decim_stages_destroy": (C.c_int, [vp]),
         "sdrx_decim_save_stages": (C.c_int, [vp, vp]),
         "sdrx_decim_load_stages": (C.c_int, [vp, vp]),
+        "sdrx_fdecim_state_bytes": (i64, [vp]),
+        "sdrx_fdecim_get_state": (C.c_int, [vp, vp]),
+        "sdrx_fdecim_set_state": (C.c_int, [vp, vp]),
+        "sdrx_chan_bank_state_bytes": (i64, [vp]),
+        "sdrx_chan_bank_get_state": (C.c_int, [vp, vp]),
+        "sdrx_chan_bank_set_state": (C.c_int, [vp, vp]),
         "sdrx_fdecim_stages_create": (C.c_int, [pp, C.c_int]),
         "sdrx_fdecim_stages_destroy": (C.c_int, [vp]),
         "sdrx_fdecim_save_stages": (C.c_int, [vp, vp]),

@@ -700,6 +700,70 @@ int sdrx_chan_bank_remove_channel(sdrx_chan_bank_t* b, int32_t c)
     return retire_dead_groups(b);
 }
 
+/* checkpoint of the filter state: per group its sample count and every stream's history (the raw stream and the node
+ * streams; the reference's ring buffers are a pure function of them).  Layout: [magic, n_groups] then per group
+ * [T, n_streams] and per stream [hist_len, hist_len x 4 bytes].  Queued, unread output is NOT part of it.  A state only
+ * fits a bank with the same channels configured in the same order (the same plan): set_state checks the shape. */
+static const int64_t CHAN_STATE_MAGIC = 0x7364727863686b31LL;      // "sdrxchk1"
+
+int64_t sdrx_chan_bank_state_bytes(const sdrx_chan_bank_t* b)
+{
+    if (!b) return SDRX_EINVAL;
+    int64_t n = 16;
+    for (const Group* g : b->groups) { n += 16; for (const Stream& s : g->streams) n += 8 + (int64_t)s.hist_len * 4; }
+    return n;
+}
+
+int sdrx_chan_bank_get_state(sdrx_chan_bank_t* b, void* host_buf)
+{
+    if (!b || !host_buf) { set_error("sdrx_chan_bank_get_state: null argument"); return SDRX_EINVAL; }
+    SDRX_HIP(hipSetDevice(b->device));
+    char* p = static_cast<char*>(host_buf);
+    auto put = [&](int64_t v) { std::memcpy(p, &v, 8); p += 8; };
+    put(CHAN_STATE_MAGIC); put((int64_t)b->groups.size());
+    for (Group* g : b->groups) {
+        put(g->T); put((int64_t)g->streams.size());
+        for (Stream& s : g->streams) {
+            put(s.hist_len);
+            SDRX_HIP(hipMemcpyAsync(p, s.hist[s.cur], (size_t)s.hist_len * 4, hipMemcpyDeviceToHost, b->stream));
+            p += (size_t)s.hist_len * 4;
+        }
+    }
+    SDRX_HIP(hipStreamSynchronize(b->stream));
+    return SDRX_OK;
+}
+
+int sdrx_chan_bank_set_state(sdrx_chan_bank_t* b, const void* host_buf)
+{
+    if (!b || !host_buf) { set_error("sdrx_chan_bank_set_state: null argument"); return SDRX_EINVAL; }
+    SDRX_HIP(hipSetDevice(b->device));
+    const char* p = static_cast<const char*>(host_buf);
+    auto get = [&]() { int64_t v; std::memcpy(&v, p, 8); p += 8; return v; };
+    // first pass: the shape must be this bank's
+    const char* q = p;
+    bool ok = get() == CHAN_STATE_MAGIC && get() == (int64_t)b->groups.size();
+    for (size_t gi = 0; ok && gi < b->groups.size(); gi++) {
+        const Group* g = b->groups[gi];
+        (void)get();
+        ok = get() == (int64_t)g->streams.size();
+        for (size_t si = 0; ok && si < g->streams.size(); si++) { ok = get() == g->streams[si].hist_len; p += (size_t)g->streams[si].hist_len * 4; }
+    }
+    if (!ok) { set_error("sdrx_chan_bank_set_state: the state was taken from a bank with another configuration"); return SDRX_EINVAL; }
+    p = q; (void)get(); (void)get();
+    SDRX_HIP(hipStreamSynchronize(b->stream));
+    for (Group* g : b->groups) {
+        g->T = get(); (void)get();
+        for (Stream& s : g->streams) {
+            (void)get();
+            SDRX_HIP(hipMemcpyAsync(s.hist[s.cur], p, (size_t)s.hist_len * 4, hipMemcpyHostToDevice, b->stream));
+            p += (size_t)s.hist_len * 4;
+        }
+    }
+    SDRX_HIP(hipStreamSynchronize(b->stream));
+    for (auto& ch : b->ch) { ch.avail = 0; ch.last_off = 0; ch.last_n = 0; }     // the queues belong to the old timeline
+    return SDRX_OK;
+}
+
 int32_t sdrx_chan_bank_group_count(const sdrx_chan_bank_t* b) { return b ? (int32_t)b->groups.size() : SDRX_EINVAL; }
 
 int sdrx_chan_bank_reset(sdrx_chan_bank_t* b)

@@ -270,6 +270,32 @@ int sdrx_fdecim_last_launch(const sdrx_fdecim_t* h, char* kernel_name, int name_
 
 } // extern "C"
 
+extern "C" {
+
+/* checkpoint of the carried state: the cascade's filter rings (6 x FD_STATE floats; stages beyond the cascade are zero) */
+int64_t sdrx_fdecim_state_bytes(const sdrx_fdecim_t*) { return (int64_t)6 * FD_STATE * sizeof(float); }
+
+int sdrx_fdecim_get_state(sdrx_fdecim_t* h, void* host_buf)
+{
+    if (!h || !host_buf) { set_error("sdrx_fdecim_get_state: null argument"); return SDRX_EINVAL; }
+    SDRX_HIP(hipSetDevice(h->device));
+    std::memset(host_buf, 0, (size_t)6 * FD_STATE * sizeof(float));
+    if (h->ns) SDRX_HIP(hipMemcpyAsync(host_buf, h->d_state[h->cur], (size_t)h->ns * FD_STATE * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    SDRX_HIP(hipStreamSynchronize(h->stream));
+    return SDRX_OK;
+}
+
+int sdrx_fdecim_set_state(sdrx_fdecim_t* h, const void* host_buf)
+{
+    if (!h || !host_buf) { set_error("sdrx_fdecim_set_state: null argument"); return SDRX_EINVAL; }
+    SDRX_HIP(hipSetDevice(h->device));
+    SDRX_HIP(hipMemcpyAsync(h->d_state[h->cur], host_buf, (size_t)6 * FD_STATE * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    SDRX_HIP(hipStreamSynchronize(h->stream));
+    return SDRX_OK;
+}
+
+} // extern "C"
+
 /* ---- one DecimatorsFI / FF / IF object, several decimateK_x: the shared six filters -------------------------------- */
 struct sdrx_fdecim_stages { int device = 0; float* d_state = nullptr; };
 

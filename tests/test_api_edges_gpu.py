@@ -124,3 +124,35 @@ def test_round2_entry_points_refuse_bad_arguments_and_take_empty_calls():
     assert L.sdrx_iir_create(C.byref(p), 0, 1, bad) == -1
     for h in (d, b, g, g1, st):
         h.close()
+
+
+def test_checkpoints_of_bank_and_float_decimators():
+    """get_state / set_state: a fresh object that is given the state continues exactly where the first one was"""
+    L = sa.lib()
+    x = synth.mix(300_000, 61, 20000, 9000)
+    rates = [48000, 48000, 12500, 2_400_000]; fcs = [100_000, -733_000, 555_555, 0]
+    a = sa.ChannelizerBank(2_400_000, rates, fcs)
+    a.feed(x[: 2 * 123_457])
+    st = np.zeros(L.sdrx_chan_bank_state_bytes(a._h), np.uint8)
+    assert L.sdrx_chan_bank_get_state(a._h, st.ctypes.data) == 0
+    for c in range(4):
+        a.skip(c)
+    a.feed(x[2 * 123_457:])
+    b = sa.ChannelizerBank(2_400_000, rates, fcs)
+    b.feed(x[:2000])                                       # something else first: set_state drops it
+    assert L.sdrx_chan_bank_set_state(b._h, st.ctypes.data) == 0
+    assert all(b.available(c) == 0 for c in range(3))
+    b.feed(x[2 * 123_457:])
+    for c in range(3):
+        assert np.array_equal(a.read(c), b.read(c)), c
+    other = sa.ChannelizerBank(2_400_000, rates[:2], fcs[:2])
+    assert L.sdrx_chan_bank_set_state(other._h, st.ctypes.data) == -1 and b"another configuration" in L.sdrx_last_error()
+    for h in (a, b, other):
+        h.close()
+    xf = np.random.default_rng(3).uniform(-0.9, 0.9, 200_000).astype(np.float32)
+    f1 = sa.FloatDecimators("fi", 6, sa.FC_CEN); f2 = sa.FloatDecimators("fi", 6, sa.FC_CEN)
+    f1.decimate(xf[:77_056])
+    fs = np.zeros(L.sdrx_fdecim_state_bytes(f1._h), np.uint8)
+    assert L.sdrx_fdecim_get_state(f1._h, fs.ctypes.data) == 0 and L.sdrx_fdecim_set_state(f2._h, fs.ctypes.data) == 0
+    assert np.array_equal(f1.decimate(xf[77_056:]), f2.decimate(xf[77_056:]))
+    f1.close(); f2.close()
