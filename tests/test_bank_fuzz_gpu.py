@@ -1,5 +1,7 @@
 """GPU: random sequences of bank operations (feeds of any length, partial reads, skips, reconfigure, add / remove channel,
 reset) against a model made of oracle chains and Python queues -- every sample of every channel, after every operation."""
+import os
+
 import numpy as np
 import pytest
 
@@ -35,7 +37,7 @@ def _rand_cfg(rng):
     return rate, int(rng.integers(-FS // 2 + rate // 2, FS // 2 - rate // 2 + 1))
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SDRX_FUZZ_SEEDS", "6"))))      # a soak run sets SDRX_FUZZ_SEEDS=200
 def test_random_operation_sequences(seed):
     rng = np.random.default_rng(1000 + seed)
     x = synth.noise_iq(600_000, 70 + seed, 32767)

@@ -3,6 +3,7 @@
 sdrx_decim_save_stages / sdrx_decim_load_stages reproduce that; the oracle's model of it (sdro_decim_switch) is pinned
 against the compiled reference object in tests/test_oracle_vs_ref.py::test_decimators_variant_switch."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -22,7 +23,7 @@ def _switch(o, log2, fc):
 @pytest.mark.parametrize("bits", (8, 12, 16))
 def test_variant_changes_on_one_object(bits):
     rng = np.random.default_rng(100 + bits)
-    for trial in range(6):
+    for trial in range(int(os.environ.get("SDRX_FUZZ_SEEDS", "6"))):
         amp = int(rng.choice([127, 2047, 32767]))
         x = synth.mix(400_000, 4000 + trial + bits, amp, 500, 1)
         obj = sa.DecimatorsObject(bits)
@@ -91,7 +92,7 @@ def test_float_decimators_variant_changes_on_one_object(kind, bits):
     """DecimatorsFI / FF / IF: the six IntHalfbandFilterEOF members are shared by all cascades of an object as well
     (oracle model pinned by tests/test_oracle_vs_ref.py::test_float_decimators_variant_switch)"""
     rng = np.random.default_rng(31 + bits)
-    for trial in range(5):
+    for trial in range(int(os.environ.get("SDRX_FUZZ_SEEDS", "5"))):
         obj = sa.FloatDecimatorsObject(kind, bits)
         o = None
         for seg in range(8):
