@@ -232,8 +232,14 @@ __global__ void __launch_bounds__(256) be_sched_dyadic_fill_kernel(const BeChan*
 }
 
 // ---- 2a. NCO mix of history + new samples into float (exact: int16 -> float, complex product)
-__global__ void be_mix_kernel(const BeChan* __restrict__ ch, const BeBufs* __restrict__ bufs, const float* __restrict__ nco_tbl)
+__global__ __launch_bounds__(256)
+void be_mix_kernel(const BeChan* __restrict__ ch, const BeBufs* __restrict__ bufs, const float* __restrict__ nco_tbl)
 {
+    // the cosine table (16 KB) is gathered twice per sample at a lane stride of `inc` entries: from LDS, not through the
+    // texture path; a workgroup takes enough samples (the host sizes the grid) to pay for staging it
+    __shared__ float tbl[BE_NCO_N];
+    for (int i = threadIdx.x; i < BE_NCO_N; i += blockDim.x) tbl[i] = nco_tbl[i];
+    __syncthreads();
     const int c = blockIdx.y;
     const BeChan s = ch[c];
     const BeBufs b = bufs[c];
@@ -242,9 +248,10 @@ __global__ void be_mix_kernel(const BeChan* __restrict__ ch, const BeBufs* __res
         const int j = i - BE_HIST;                          // sample index relative to this feed; < 0: history
         const uint32_t v = j < 0 ? b.hist[i] : b.in[j];
         // phase after nextPhase() for this sample; s.nco_phase is still the phase BEFORE this feed
-        long p = ((long)s.nco_phase + (long)(j + 1) * (long)s.nco_inc) % BE_NCO_N;
-        if (p < 0) p += BE_NCO_N;
-        const float o_r = nco_tbl[p], o_i = -nco_tbl[(p + BE_NCO_N / 4) % BE_NCO_N];
+        // (phase + (j + 1) * inc) mod 4096, non-negative -- what NCO::nextPhase's add-and-wrap loop arrives at; in 24-bit
+        // arithmetic on the residues (the table size is a power of two, so the masks are exact for negative j + 1 and inc too)
+        const uint32_t p = ((uint32_t)s.nco_phase + ((uint32_t)(j + 1) & (BE_NCO_N - 1)) * ((uint32_t)s.nco_inc & (BE_NCO_N - 1))) & (BE_NCO_N - 1);
+        const float o_r = tbl[p], o_i = -tbl[(p + BE_NCO_N / 4) & (BE_NCO_N - 1)];
         const float a = (float)(int16_t)(v & 0xffffu), q = (float)(int16_t)(v >> 16);
         float2 m; m.x = a * o_r - q * o_i; m.y = a * o_i + q * o_r;         // std::complex<float> operator*=
         b.mixed[i] = m;
@@ -531,6 +538,8 @@ __global__ void be_finish_kernel(BeChan* __restrict__ ch, const BeBufs* __restri
         if (s.discri == 0) { b.cplx_out[j] = v; continue; }
         if (s.discri == 1) {
             const float cur = atan2_approx2(v.y, v.x);
+            // (taking the left neighbour's `cur` instead of recomputing it changes nothing: the kernel moves 36 bytes per
+            // output at ~6 TB/s -- it is at the memory roofline)
             const float prev = j == 0 ? s.prev_arg : [&] { const float2 pv = sample(j - 1); return atan2_approx2(pv.y, pv.x); }();
             float dev = (float)((double)(cur - prev) / 3.14159265358979323846);
             if (dev < -1.0f) dev += 2.0f; else if (dev > 1.0f) dev -= 2.0f;

@@ -354,7 +354,9 @@ static int feed_common(sdrx_backend* b, const int16_t* const* d_iq, const int64_
         SDRX_HIP(hipEventRecord(b->prod_ev, producer));
         SDRX_HIP(hipStreamWaitEvent(b->stream, b->prod_ev, 0));
     }
-    hipLaunchKernelGGL(be_mix_kernel, dim3(gx, (unsigned)b->n_ch), dim3(256), 0, b->stream, b->d_chan, b->d_bufs, b->d_nco);
+    // be_mix stages the 16 KB NCO table per workgroup: at least 8192 samples each
+    const unsigned gx_mix = (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, (n_max + BE_HIST + 8191) / 8192));
+    hipLaunchKernelGGL(be_mix_kernel, dim3(gx_mix, (unsigned)b->n_ch), dim3(256), 0, b->stream, b->d_chan, b->d_bufs, b->d_nco);
     SDRX_HIP(hipGetLastError());
     if (producer && producer != b->stream) {
         SDRX_HIP(hipEventRecord(b->cons_ev, b->stream));
