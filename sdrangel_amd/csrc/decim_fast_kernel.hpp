@@ -29,10 +29,30 @@ constexpr int DF_WARM = 4;            // warm-up sub-chunks
 constexpr int DF_CHUNK = 4096;        // flag granularity == DC_CHUNK of the EXACT kernel
 
 // generic packed-int16 stage, R outputs (I and Q) per lane; see stage_pk16_r8 for the derivation
+// The packed tap pair of output r and window dword d depends on e = r - 2d only (pk_coef): DF_NCOEF values, a third of
+// them non-zero.  DF_SGPR_COEF = 1 holds them in SGPRs (filled once per kernel) instead of 32-bit literals in every v_dot2c.
+#ifndef DF_SGPR_COEF
+#define DF_SGPR_COEF 1
+#endif
+constexpr int DF_NCOEF = 48, DF_COEF_BIAS = 40;
+struct DfCoef { uint32_t v[DF_NCOEF]; };
+template<int ORDER, int MODE> __device__ __forceinline__ void df_coef_fill(DfCoef& c)
+{
+    static_for<0, DF_NCOEF>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int e = i - DF_COEF_BIAS;                  // r - 2d; with d = 0: r = e
+        constexpr int lo = hb_tap<ORDER>(e + 32), hi = hb_tap<ORDER>(e + 31);
+        constexpr uint32_t val = pk16(MODE != MODE_CEN ? -lo : lo, hi);
+        uint32_t x = val;
+        if constexpr (val != 0) asm volatile("s_mov_b32 %0, %1" : "=s"(x) : "i"(val));
+        c.v[i] = x;
+    });
+}
+
 template<int ORDER, int MODE, int SHL, int R>
 __device__ __forceinline__ void stage_pk16(const uint32_t* __restrict__ oI, const uint32_t* __restrict__ oQ,
                                            const uint32_t* __restrict__ eI, const uint32_t* __restrict__ eQ,
-                                           int t, int (&yI)[R], int (&yQ)[R])
+                                           int t, int (&yI)[R], int (&yQ)[R], const DfCoef& ctab)
 {
     constexpr int P = hb_pairs<ORDER>();
     constexpr int CD = P - 1;
@@ -85,7 +105,10 @@ __device__ __forceinline__ void stage_pk16(const uint32_t* __restrict__ oI, cons
         static_for<0, NW>([&](auto dc) {
             constexpr int d = decltype(dc)::value;
             constexpr uint32_t cf = pk_coef<ORDER, MODE>(r, d);
-            if constexpr (cf != 0) { aI = dot2(wI[d], cf, aI); aQ = dot2(wQ[d], cf, aQ); }
+            if constexpr (cf != 0) {
+                if constexpr (DF_SGPR_COEF) { const uint32_t cs = ctab.v[r - 2 * d + DF_COEF_BIAS]; aI = dot2(wI[d], cs, aI); aQ = dot2(wQ[d], cs, aQ); }
+                else { aI = dot2(wI[d], cf, aI); aQ = dot2(wQ[d], cf, aQ); }
+            }
         });
         yI[r] = (int)((uint32_t)aI << SHL) >> (HB_SHIFT - 1);
         yQ[r] = (int)((uint32_t)aQ << SHL) >> (HB_SHIFT - 1);
@@ -224,6 +247,9 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
 
     for (int i = lane; i < df_lds_dwords(L, S); i += NT) lds[i] = 0;
 
+    DfCoef ctab_cen, ctab_rot;
+    if constexpr (DF_SGPR_COEF) { df_coef_fill<64, MODE_CEN>(ctab_cen); df_coef_fill<64, MODE_INF>(ctab_rot); }
+
     QT pre[LPT];
     // A sub-chunk is either wholly history (sub < 0) or wholly input: the source is chosen with a wave-uniform (scalar)
     // branch and the only per-lane test is a 32-bit compare against the quads left in the stream.
@@ -266,7 +292,7 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
             if constexpr (s <= 3) {
                 constexpr int R = 16 >> s;                     // 8, 4, 2
                 int yI[R], yQ[R];
-                stage_pk16<64, MODE, (s == 1 ? PRE : 0), R>(iI, iQ, jI, jQ, lane, yI, yQ);
+                stage_pk16<64, MODE, (s == 1 ? PRE : 0), R>(iI, iQ, jI, jQ, lane, yI, yQ, MODE == MODE_CEN ? ctab_cen : ctab_rot);
                 if constexpr (s < L) {
                     if constexpr (s + 1 <= 3) {
                         // these outputs are re-read as int16: y fits iff (y + 0x8000) has no bit above 15.  add + or
