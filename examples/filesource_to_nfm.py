@@ -4,6 +4,8 @@
     .sdriq file (FileRecord header + int16 I/Q)  ->  SampleSinkFifo  ->  engine drain loop
         ->  DC offset correction (work()'s iqCorrections)  ->  DownChannelizer bank (N channels)
         ->  per channel NCO -> Interpolator -> phaseDiscriminatorDelta (the NFM demod front)  ->  float audio-rate streams
+        ->  (second leg) the same front with complex output -> NFM audio tail: discriminator, power squelch, gate delay
+            line, 301-tap Bandpass, volume -> qint16 PCM, what NFMDemod::feed pushes into its AudioFifo
 
     python examples/filesource_to_nfm.py [out_dir]          # writes a synthetic recording, replays it, saves the results
 
@@ -56,8 +58,18 @@ def main(out_dir):
         cfgs.append(sa.BackendCfg(in_rate=out_rate, nco_freq=-ofs, out_rate=48000, interp_cutoff=12500 / 2.2, taps_per_phase=4.5,
                                   filt_mode=0, f1=0.0, f2=0.0, discri=1, fm_scaling=48000 / 2500))
     front = sa.BackendBank(cfgs)
+    # second leg: complex samples out of the front, then the audio-rate tail of NFMDemod::feed (nfmdemod.cpp:160-300)
+    cfgs_c = []
+    for c in range(len(fcs)):
+        _modes, out_rate, ofs = bank.info(c)
+        cfgs_c.append(sa.BackendCfg(in_rate=out_rate, nco_freq=-ofs, out_rate=48000, interp_cutoff=12500 / 2.2, taps_per_phase=4.5,
+                                    filt_mode=0, f1=0.0, f2=0.0, discri=0, fm_scaling=1.0))
+    front_c = sa.BackendBank(cfgs_c)
+    tail = sa.AudioTail([sa.AudioTailCfg(kind=0, audio_rate=48000, volume=2.0, fm_scaling=48000 / (2 * 2500.0), squelch_level=1e-6,
+                                         squelch_gate=480, af_bandwidth=3000.0) for _ in fcs])
 
     audio = [[] for _ in fcs]
+    pcm = [[] for _ in fcs]
     block = 2 * 50_000                                      # int16 per "FileSourceThread tick"
     for pos in range(0, payload.size, block):
         fifo.write(payload[pos: pos + block])
@@ -67,6 +79,10 @@ def main(out_dir):
             bank.feed(span)
             chans = [bank.read(c) for c in range(len(fcs))]
             front.feed(chans)
+            front_c.feed(chans)
+            cplx = [front_c.read(c) for c in range(len(fcs))]
+            for c, y16 in enumerate(tail.feed(cplx)):
+                pcm[c].append(y16.copy())
             for c in range(len(fcs)):
                 audio[c].append(front.read(c))
     for c, fc in enumerate(fcs):
@@ -76,7 +92,15 @@ def main(out_dir):
         spec = np.abs(np.fft.rfft(y[2000:] - y[2000:].mean()))
         f_peak = np.argmax(spec) * 48000.0 / (2 * (spec.size - 1))
         print(f"channel {c}: fc {fc:+8d} Hz  {y.size} samples at 48 kS/s, dominant tone {f_peak:7.1f} Hz (sent {700 + 300 * c} Hz)")
+    for c in range(len(fcs)):
+        z = np.concatenate(pcm[c]).astype(np.float64)
+        np.save(os.path.join(out_dir, f"nfm_pcm_ch{c}.npy"), z.astype(np.int16))
+        zs = z[4000:]
+        spec = np.abs(np.fft.rfft(zs - zs.mean()))
+        f_peak = np.argmax(spec) * 48000.0 / (2 * (spec.size - 1))
+        print(f"channel {c}: qint16 audio {z.size} samples, peak |s| {int(np.abs(z).max())}, dominant tone {f_peak:7.1f} Hz")
     print(f"{n} input samples replayed from {rec}")
+    main.pcm = pcm
     return audio
 
 

@@ -19,3 +19,10 @@ def test_filesource_replay_recovers_the_modulating_tones(tmp_path):
         s = np.abs(np.fft.rfft(y - y.mean()))
         f_peak = np.argmax(s) * 48000.0 / (2 * (s.size - 1))
         assert abs(f_peak - (700 + 300 * c)) < 20.0, (c, f_peak)
+    # second leg: the qint16 audio out of the NFM tail (squelch open on every carrier) carries the same tone
+    for c, parts in enumerate(mod.main.pcm):
+        z = np.concatenate(parts).astype(np.float64)[4000:]
+        assert np.abs(z).max() > 100, c                      # the squelch opened
+        s = np.abs(np.fft.rfft(z - z.mean()))
+        f_peak = np.argmax(s) * 48000.0 / (2 * (s.size - 1))
+        assert abs(f_peak - (700 + 300 * c)) < 20.0, (c, f_peak)
