@@ -49,3 +49,24 @@ def test_real_engine_and_gpu_engine_agree_in_one_process():
     assert out.returncode == 0, (out.returncode, out.stdout[-3000:], out.stderr[-2000:])
     assert "ENGINE DROP-IN: ALL OK" in out.stdout
     assert out.stdout.count("identical") == 3 + 3 + 1 and "DIFFERENT" not in out.stdout and "FAIL" not in out.stdout
+
+
+def test_reference_sdrangelbench_sources_run_on_the_gpu_classes():
+    """oracle/_ref/sdrangelbench_gpu = the reference's OWN sdrbench/mainbench.cpp + parserbench.cpp, compiled unchanged against
+    qt_adapter/shadow/ (its Decimators / DecimatorsIF / FI / FF members are sdrx:: classes): every test type runs and prints
+    the reference's result line.  (The samples themselves are checked by tests/test_sdrxbench_gpu.py on the same data.)"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "sdrangelbench_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/sdrangelbench_gpu not built (make -C oracle dropin_bench, build container only)")
+    env = dict(os.environ)
+    sys_stdcpp = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
+    if os.path.exists(sys_stdcpp):
+        env["LD_PRELOAD"] = sys_stdcpp
+    for test, prefix in (("decimateii", "testDecimateII"), ("decimateinfii", "testDecimateII"), ("decimatesupii", "testDecimateII"),
+                         ("decimatefi", "testDecimateFI"), ("decimateff", "testDecimateFF"), ("decimateif", "testDecimateIF")):
+        for log2 in (0, 4, 6):
+            out = subprocess.run([exe, "-t", test, "-l", str(log2), "-n", "2000000", "-r", "3"], capture_output=True, text=True, timeout=300, env=env)
+            text = out.stdout + out.stderr
+            assert out.returncode == 0, (test, log2, text[-2000:])
+            assert f"MainBench::{prefix}: ran test in" in text and "kS/s" in text, (test, log2, text[-1000:])
+            assert "sdrx" not in text.lower() or "error" not in text.lower(), text[-1000:]
