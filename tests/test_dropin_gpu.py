@@ -70,3 +70,27 @@ def test_reference_sdrangelbench_sources_run_on_the_gpu_classes():
             assert out.returncode == 0, (test, log2, text[-2000:])
             assert f"MainBench::{prefix}: ran test in" in text and "kS/s" in text, (test, log2, text[-1000:])
             assert "sdrx" not in text.lower() or "error" not in text.lower(), text[-1000:]
+
+
+@pytest.mark.parametrize("log2,fcpos,bits", [(4, 2, 1), (6, 0, 1), (3, 1, 2), (5, 2, 0), (1, 0, 2), (0, 2, 1)])
+def test_reference_device_thread_unchanged_on_gpu_decimators(log2, fcpos, bits, tmp_path):
+    """plugins/samplesource/testsource/testsourcethread.cpp, compiled unchanged twice (oracle/dropin_thread_test.cpp): against the
+    reference's Decimators and against qt_adapter/shadow (GPU classes).  Both feed the reference's SampleSinkFifo from a timer; the
+    stream does not depend on the timer (2.56 MS/s: whole decimation groups per elapsed ms), only its length does -- the common
+    prefix must be identical, sample for sample."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "testsource_ref"); gpu = os.path.join(ROOT, "oracle", "_ref", "testsource_gpu")
+    if not (os.path.exists(ref) and os.path.exists(gpu)):
+        pytest.skip("oracle/_ref/testsource_{ref,gpu} not built (make -C oracle dropin_thread, build container only)")
+    env = dict(os.environ)
+    sys_stdcpp = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
+    if os.path.exists(sys_stdcpp):
+        env["LD_PRELOAD"] = sys_stdcpp
+    outs = []
+    for exe, name in ((ref, "ref.bin"), (gpu, "gpu.bin")):
+        path = str(tmp_path / name)
+        r = subprocess.run([exe, str(log2), str(fcpos), str(bits), path, "14"], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, (exe, r.stdout[-500:], r.stderr[-1500:])
+        outs.append(open(path, "rb").read())
+    n = min(len(outs[0]), len(outs[1]))
+    assert n >= 4 * 1000, (len(outs[0]), len(outs[1]))
+    assert outs[0][:n] == outs[1][:n], (log2, fcpos, bits, n // 4)
