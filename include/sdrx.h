@@ -466,6 +466,24 @@ int sdrx_dccorr_set_stream(sdrx_dccorr_t* h, void* hip_stream);
  * (sum of int32 over n_bytes, best of reps launches) reaches on this box.  Not part of the sample path. */
 int sdrx_measure_hbm_read(int device, uint64_t n_bytes, int32_t reps, double* gb_per_s);
 
+/* ------------------------------------------------------------------------------------------
+ * Fan-out of one staged source stream to several GPUs by peer copies (xGMI on an 8 x MI355X node): SURVEY 8e's optional
+ * staging path -- "one stream per GPU, xGMI only for fan-out, no collective on the per-sample path".  A stream uploaded (or
+ * decimated) once on `src_device` is copied point-to-point into one buffer per destination GPU, each on its own stream;
+ * the consumers (e.g. one channelizer bank per GPU over the same 61.44 MS/s stream) read their local copy.
+ *   send      asynchronous; the copies start when what `producer_stream` (on src_device; NULL = everything queued on the
+ *             legacy stream) holds so far is done
+ *   buffer    destination i's device pointer (on dst_devices[i]); valid contents after wait / stream_wait
+ *   wait      host waits for destination i;  stream_wait: a consumer stream on that GPU waits instead (device-ordered)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sdrx_fanout sdrx_fanout_t;
+int sdrx_fanout_create(sdrx_fanout_t** f, int src_device, int32_t n_dst, const int32_t* dst_devices, int64_t max_bytes);
+int sdrx_fanout_destroy(sdrx_fanout_t* f);
+int sdrx_fanout_send(sdrx_fanout_t* f, const void* d_src, int64_t bytes, void* producer_stream);
+void* sdrx_fanout_buffer(sdrx_fanout_t* f, int32_t i);
+int sdrx_fanout_wait(sdrx_fanout_t* f, int32_t i);
+int sdrx_fanout_stream_wait(sdrx_fanout_t* f, int32_t i, void* consumer_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -153,6 +153,12 @@ def lib() -> C.CDLL:
         "sdrx_decim_stages_destroy": (C.c_int, [vp]),
         "sdrx_decim_save_stages": (C.c_int, [vp, vp]),
         "sdrx_decim_load_stages": (C.c_int, [vp, vp]),
+        "sdrx_fanout_create": (C.c_int, [pp, C.c_int, i32, vp, i64]),
+        "sdrx_fanout_destroy": (C.c_int, [vp]),
+        "sdrx_fanout_send": (C.c_int, [vp, vp, i64, vp]),
+        "sdrx_fanout_buffer": (vp, [vp, i32]),
+        "sdrx_fanout_wait": (C.c_int, [vp, i32]),
+        "sdrx_fanout_stream_wait": (C.c_int, [vp, i32, vp]),
         "sdrx_fdecim_state_bytes": (i64, [vp]),
         "sdrx_fdecim_get_state": (C.c_int, [vp, vp]),
         "sdrx_fdecim_set_state": (C.c_int, [vp, vp]),
@@ -392,6 +398,32 @@ class DecimatorsU(Decimators):
         n = C.c_int32()
         _check(lib().sdrx_decim_process_u8(self._h, buf.ctypes.data, buf.size, out.ctypes.data, C.byref(n)), "sdrx_decim_process_u8")
         return out[: 2 * n.value]
+
+
+class Fanout:
+    """One staged source stream copied to several GPUs point-to-point (sdrx_fanout_*; xGMI peer copies on a multi-GPU node)."""
+
+    def __init__(self, src_device: int, dst_devices, max_bytes: int):
+        d = np.ascontiguousarray(dst_devices, dtype=np.int32)
+        self.n = d.size
+        self._h = C.c_void_p()
+        _check(lib().sdrx_fanout_create(C.byref(self._h), src_device, self.n, d.ctypes.data, max_bytes), "sdrx_fanout_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sdrx_fanout_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def send(self, d_src: int, n_bytes: int, producer_stream: int | None = None):
+        _check(lib().sdrx_fanout_send(self._h, d_src, n_bytes, producer_stream), "sdrx_fanout_send")
+
+    def buffer(self, i: int) -> int:
+        return lib().sdrx_fanout_buffer(self._h, i) or 0
+
+    def wait(self, i: int):
+        _check(lib().sdrx_fanout_wait(self._h, i), "sdrx_fanout_wait")
 
 
 class FloatDecimStages:
