@@ -68,6 +68,16 @@ static int max_levels()
     return TK_DEFAULT_LEVELS;
 }             // < the 159 KB of dynamic LDS the kernel may ask for
 
+// Half-band engine of the bank's kernels: the matrix cores (i8 MFMA, hb_mfma.hpp) unless SDRX_CHAN_ENGINE=valu asks for the
+// dot2 kernel of rounds 1-2 (both are gfx950 code, both bit-exact; tests run the matrix under each).  Read at plan time.
+static bool engine_mfma()
+{
+    const char* e = getenv("SDRX_CHAN_ENGINE");
+    return !(e && strcmp(e, "valu") == 0);
+}
+// a level runs on the matrix cores when an entry fills whole tiles (16 blocks of 16 outputs per component and chunk)
+static bool level_is_mfma(bool engine, int rel) { return engine && (TK_CHUNK >> rel) >= 256; }
+
 struct HNode {
     int parent = -1, mode = 0, depth = 0;
     int child[3] = { -1, -1, -1 };
@@ -111,6 +121,7 @@ struct Group {
     std::vector<TkArray> arrays;
     std::vector<SinkInfo> sinks;
     int max_lds_dw = 0;
+    bool mfma = true;             // engine this group was planned for
     void* d_static = nullptr;     // subtrees | nodes | arrays
     TkSubtree* d_subtrees = nullptr; TkNode* d_nodes = nullptr; TkArray* d_arrays = nullptr;
 };
@@ -207,6 +218,7 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
     }
 
     g->streams.clear(); g->passes.clear(); g->subtrees.clear(); g->nodes.clear(); g->arrays.clear(); g->sinks.clear();
+    g->mfma = engine_mfma();
     { Stream raw; raw.trie_node = 0; raw.depth = 0; raw.pass = 0; g->streams.push_back(std::move(raw)); g->trie[0].stream = 0; }
 
     for (size_t si = 0; si < g->streams.size(); si++) {
@@ -236,15 +248,17 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
             const int len = arm_len(rel);
             if (rel != cur_level) { cur_level = rel; reg_used[rel & 1] = 0; }
             // returns the INDEX of the array (relative to the subtree's list); node fields are patched to offsets later
-            auto take = [&]() {
+            auto take = [&](bool odd_arm = false) {
                 const int idx = (int)g->arrays.size() - st.array_base;
-                g->arrays.push_back(TkArray{ reg_used[rel & 1], len, rel & 1, 0 });   // store: region id for now
+                // an odd arm read by an MFMA level holds x ^ 0x0080 (hb_mfma.hpp): the consumers of an array sit one level down
+                const int bias = odd_arm && level_is_mfma(g->mfma, rel + 1) ? 1 : 0;
+                g->arrays.push_back(TkArray{ reg_used[rel & 1], len, rel & 1, bias });   // store: region id for now
                 reg_used[rel & 1] += len; reg_size[rel & 1] = std::max(reg_size[rel & 1], reg_used[rel & 1]);
                 return idx;
             };
             a.E[0] = take(); a.E[1] = take();
-            if (c) { a.O[0] = take(); a.O[1] = take(); }
-            if (lu) { a.A[0] = take(); a.A[1] = take(); }
+            if (c) { a.O[0] = take(true); a.O[1] = take(true); }
+            if (lu) { a.A[0] = take(true); a.A[1] = take(true); }
             return a;
         };
         std::vector<int> cur{ root };
@@ -258,6 +272,10 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
             lv.node_base = rel_nodes;
             lv.nout = TK_CHUNK >> rel;
             lv.r_log2 = 3; lv.jobs_log2 = 0;                           // fixed up below once the level's entry count is known
+            lv.mfma = level_is_mfma(g->mfma, rel) ? 1 : 0;
+            lv.tpe_log2 = 0; while ((256 << lv.tpe_log2) < lv.nout) lv.tpe_log2++;
+            lv.xm = rel < levels && level_is_mfma(g->mfma, rel + 1) ? HBM_BIAS2 : 0u;
+            lv.pad = 0;
             lv.arr_base = (int)g->arrays.size() - st.array_base;
             int n_entries = 0;
             for (size_t pi = 0; pi < cur.size(); pi++) {
@@ -303,7 +321,7 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
                     TkNode nd; memset(&nd, 0xff, sizeof nd);
                     nd.oddI = pa.O[0]; nd.oddQ = pa.O[1]; nd.cenI = pa.E[0]; nd.cenQ = pa.E[1];
                     fill(nd.a, SDRX_MODE_CENTER);
-                    nd.b.present = 0;
+                    nd.b.present = 0; nd.mode_a = SDRX_MODE_CENTER;
                     g->nodes.push_back(nd); n_entries++;
                 }
                 if (kid[SDRX_MODE_LOWER] >= 0 || kid[SDRX_MODE_UPPER] >= 0) {
@@ -313,9 +331,9 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
                     nd.oddI = pa.A[0]; nd.oddQ = pa.A[1]; nd.cenI = pa.E[1]; nd.cenQ = pa.E[0];   // I <- eQ, Q <- eI
                     nd.b.present = 0;
                     if (kid[SDRX_MODE_LOWER] >= 0) {
-                        fill(nd.a, SDRX_MODE_LOWER);
+                        fill(nd.a, SDRX_MODE_LOWER); nd.mode_a = SDRX_MODE_LOWER;
                         if (kid[SDRX_MODE_UPPER] >= 0) fill(nd.b, SDRX_MODE_UPPER);
-                    } else fill(nd.a, SDRX_MODE_UPPER);
+                    } else { fill(nd.a, SDRX_MODE_UPPER); nd.mode_a = SDRX_MODE_UPPER; }
                     g->nodes.push_back(nd); n_entries++;
                 }
             }
@@ -342,6 +360,7 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
             a.off += reg_base[a.store]; a.store = store_base + 16 * i;
         }
         auto fix = [&](int& v) { if (v >= 0) v = g->arrays[(size_t)(st.array_base + v)].off; };
+        st.root_xm = level_is_mfma(g->mfma, 1) ? HBM_BIAS2 : 0u;
         { Arms r = root_arms; for (int q = 0; q < 2; q++) { fix(r.E[q]); fix(r.O[q]); fix(r.A[q]); }
           st.rootE_I = r.E[0]; st.rootE_Q = r.E[1]; st.rootO_I = r.O[0]; st.rootO_Q = r.O[1]; st.rootA_I = r.A[0]; st.rootA_Q = r.A[1]; }
         for (int i = 0; i < rel_nodes; i++) {
@@ -351,6 +370,11 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
                 if (!o->present) continue;
                 fix(o->outE_I); fix(o->outE_Q); fix(o->outO_I); fix(o->outO_Q); fix(o->outA_I); fix(o->outA_Q);
             }
+        }
+        for (int i = 0; i < st.n_arrays; i++) {
+            // the matrix-core levels read their windows as aligned 16-byte vectors
+            const TkArray& a = g->arrays[(size_t)(st.array_base + i)];
+            if (a.bias && (a.off & 3)) { set_error("internal: MFMA window not 16-byte aligned"); return SDRX_EINVAL; }
         }
         st.node_tab = store_base + 16 * st.n_arrays;
         st.arr_tab = st.node_tab + rel_nodes * TK_NODE_DW;
@@ -555,11 +579,15 @@ static int feed_group(sdrx_chan_bank* b, Group* g, const uint32_t* d_in, int64_t
         const int s0 = ps.front(), cnt = (int)ps.size();
         size_t lds_bytes = 0;                              // per pass: a deep pass must not cost the shallow ones their occupancy
         for (int si : ps) lds_bytes = std::max(lds_bytes, (size_t)g->subtrees[(size_t)g->streams[(size_t)si].subtree].lds_dwords * 4);
-        hipLaunchKernelGGL(tree_kernel, dim3((unsigned)max_segs, (unsigned)cnt), dim3(TK_THREADS), lds_bytes, b->stream,
-                           g->d_subtrees, g->d_nodes, g->d_arrays, d_streams + s0, d_sinks);
+        if (g->mfma)
+            hipLaunchKernelGGL(tree_kernel<true>, dim3((unsigned)max_segs, (unsigned)cnt), dim3(TK_THREADS), lds_bytes, b->stream,
+                               g->d_subtrees, g->d_nodes, g->d_arrays, d_streams + s0, d_sinks);
+        else
+            hipLaunchKernelGGL(tree_kernel<false>, dim3((unsigned)max_segs, (unsigned)cnt), dim3(TK_THREADS), lds_bytes, b->stream,
+                               g->d_subtrees, g->d_nodes, g->d_arrays, d_streams + s0, d_sinks);
         SDRX_HIP(hipGetLastError());
         if (p == 0) {
-            snprintf(b->last_name, sizeof b->last_name, "tree_kernel");
+            snprintf(b->last_name, sizeof b->last_name, g->mfma ? "tree_kernel<mfma>" : "tree_kernel<valu>");
             b->last_grid = (int)(max_segs * cnt); b->last_block = TK_THREADS; b->last_lds = (int)lds_bytes;
         }
     }
@@ -613,7 +641,8 @@ int sdrx_chan_bank_create(sdrx_chan_bank_t** out, int device, int32_t in_rate, i
     hipError_t e = hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete b; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
     b->stream = b->own_stream;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tree_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tree_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { sdrx_chan_bank_destroy(b); return hip_fail(e, "hipFuncSetAttribute", __FILE__, __LINE__); }
     b->ch.resize((size_t)n_ch);
     std::vector<int> all;

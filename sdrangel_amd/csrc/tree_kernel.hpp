@@ -20,6 +20,7 @@
 // the int16 store discards.
 #pragma once
 #include "hb_common.hpp"
+#include "hb_mfma.hpp"
 
 namespace sdrx {
 
@@ -48,7 +49,8 @@ struct TkNode {                 // 32 dwords
     int cenI, cenQ;             // even-arm arrays feeding the I / Q accumulators (swapped for L/U)
     TkOut a;                    // the stage itself (the LOWER child when fused)
     TkOut b;                    // the UPPER sibling when fused (present = 1)
-    int pad[4];
+    int mode_a;                 // SDRX_MODE_* of `a` (the MFMA path derives the centre-tap signs from it)
+    int pad[3];
 };
 static_assert(sizeof(TkOut) == 48 && sizeof(TkNode) == TK_NODE_DW * 4, "node table layout");
 
@@ -57,6 +59,10 @@ struct TkLevel {
     int arr_base, arr_cnt;                       // arrays PRODUCED by this level's stages (relative to the subtree's array list)
     int r_log2;                                  // outputs per job: 8, 4 or 2
     int in_len;                                  // dwords of every array this level READS (its parents' arms)
+    int mfma;                                    // 1: the level runs on the matrix cores (hb_mfma.hpp): nout >= 256, whole jobs per entry
+    int tpe_log2;                                // jobs per entry = nout / 256 (a job = 16 blocks of 16 outputs, I and Q = two MFMA tiles)
+    uint32_t xm;                                 // XORed into the odd-arm dwords this level PRODUCES: HBM_BIAS2 if the next level is an MFMA level
+    int pad;
 };
 
 struct TkSubtree {
@@ -72,6 +78,8 @@ struct TkSubtree {
     int node_tab;               // LDS dword offset of the node table copy
     int arr_tab;                // LDS dword offset of the array table copy: off | store << 16, one dword per array
     int rootE_I, rootE_Q, rootO_I, rootO_Q, rootA_I, rootA_Q;   // root arms (-1: none)
+    uint32_t root_xm;           // XORed into the root odd arms (HBM_BIAS2 if level 1 is an MFMA level)
+    int pad0;
     TkLevel lv[TK_MAX_LEVELS];
 };
 
@@ -80,7 +88,7 @@ struct TkSubtree {
 // level l+2 reuses the space: 61 KB -> 40 KB for the cfg-3 raw pass, 2 -> 4 workgroups per CU); the 16-dword
 // history survives in a persistent slot `store`: saved when the consumer level is done, restored in front of
 // the window before the producer writes the next chunk.
-struct TkArray { int off, len, store, pad; };
+struct TkArray { int off, len, store, bias; };     // bias = 1: an odd arm an MFMA level reads: its zero history is HBM_BIAS2
 
 struct TkStream {               // per feed, per input stream of a pass
     const uint32_t* hist;       // hist_len samples: absolute positions [t_old - hist_len, t_old)
@@ -108,6 +116,9 @@ __device__ __forceinline__ int div_pow2_trunc(int v, int n)
     return (v + ((v >> 31) & ((1 << n) - 1))) >> n;
 }
 
+// MX = true: levels flagged `mfma` by the planner run on the matrix cores (the default engine); MX = false is the
+// all-VALU kernel of rounds 1-2 (SDRX_CHAN_ENGINE=valu), kept as the second opinion the tests compare with.
+template<bool MX>
 __global__ __launch_bounds__(TK_THREADS, 4)
 void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restrict__ nodes,
                  const TkArray* __restrict__ arrays, const TkStream* __restrict__ streams,
@@ -140,7 +151,21 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
         // dependent global load in front of the stores
         const uint32_t* sk = reinterpret_cast<const uint32_t*>(sinks + st.sink_base);
         for (int i = tid; i < st.n_sinks * TK_SINK_DW; i += NT) lds[st.sink_tab + i] = sk[i];
+        if constexpr (MX) {
+            // odd arms an MFMA level reads carry 0x0080 in every int16 (hb_mfma.hpp): so does their zero history
+            for (int i = tid; i < st.n_arrays * 16; i += NT) {
+                const TkArray a = arrays[st.array_base + (i >> 4)];
+                if (a.bias) lds[a.store + (i & 15)] = HBM_BIAS2;
+            }
+        }
     }
+    // matrix-core operands: the order-48 taps as a banded Toeplitz block, built once per wave
+    typedef HbMfmaTaps<48, false> Taps;
+    Taps taps;
+    const int lane = tid & 63, n16 = lane & 15, g4 = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (MX) taps.init(lane);
+    const uint32_t root_xm = MX ? st.root_xm : 0u;
 
     uint4 pre[LPT];
     auto fetch = [&](long chunk) {
@@ -173,11 +198,11 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
             const uint32_t oQ = __builtin_amdgcn_perm(v.w, v.y, 0x07060302u);
             lds[st.rootE_I + q] = __builtin_amdgcn_perm(v.z, v.x, 0x05040100u);
             lds[st.rootE_Q + q] = __builtin_amdgcn_perm(v.z, v.x, 0x07060302u);
-            if (st.rootO_I >= 0) { lds[st.rootO_I + q] = oI; lds[st.rootO_Q + q] = oQ; }
+            if (st.rootO_I >= 0) { lds[st.rootO_I + q] = oI ^ root_xm; lds[st.rootO_Q + q] = oQ ^ root_xm; }
             if (st.rootA_I >= 0) {
                 // odd-arm index m even (low half) -> wrap-negated, m odd -> as is
-                lds[st.rootA_I + q] = ((0u - oI) & 0xffffu) | (oI & 0xffff0000u);
-                lds[st.rootA_Q + q] = ((0u - oQ) & 0xffffu) | (oQ & 0xffff0000u);
+                lds[st.rootA_I + q] = (((0u - oI) & 0xffffu) | (oI & 0xffff0000u)) ^ root_xm;
+                lds[st.rootA_Q + q] = (((0u - oQ) & 0xffffu) | (oQ & 0xffff0000u)) ^ root_xm;
             }
         }
         for (int i = tid; i < st.root_arr_cnt * 16; i += NT) {                 // history in front of the root windows
@@ -207,6 +232,104 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                         lds[(a >> 16) + (k & 15)] = lds[(a & 0xffffu) + lv.in_len - 16 + (k & 15)];
                     }
                 }
+            }
+            if (MX && lv.mfma) {
+                // ---- the level on the matrix cores (hb_mfma.hpp).  A job = 16 blocks of 16 consecutive outputs of ONE table entry,
+                // I and Q: two tiles, column n = block 16 tb + n; lane (n, g) ends up with outputs 4g .. 4g+3 of its block for both
+                // components = one packed dword for the even and one for the odd arm of the children.  Each wave takes a contiguous
+                // run of the level's jobs; everything that describes the entry is wave-uniform (scalar loads, scalar branches).
+                typedef const int __attribute__((address_space(4))) cint;
+                const int njobs = lv.n_nodes << lv.tpe_log2;
+                const int per = (njobs + NT / 64 - 1) / (NT / 64);
+                const int t0 = wv * per, t1 = t0 + per < njobs ? t0 + per : njobs;
+                const v4i bias = { Taps::BIAS, Taps::BIAS, Taps::BIAS, Taps::BIAS };
+                const uint32_t xm = lv.xm;
+                for (int tt = t0; tt < t1; tt++) {
+                    const int ent = tt >> lv.tpe_log2, tb = tt & ((1 << lv.tpe_log2) - 1);
+                    // the entry's descriptor: four wide scalar loads issued together (one wait), not one s_load per field
+                    typedef int s4i __attribute__((ext_vector_type(4)));
+                    typedef int s8i __attribute__((ext_vector_type(8)));
+                    cint* row = (cint*)reinterpret_cast<const int*>(nodes + st.node_base + lv.node_base + ent);
+                    const s4i rd = *reinterpret_cast<const s4i __attribute__((address_space(4)))*>(row);          // oddI, oddQ, cenI, cenQ
+                    const s8i da = *reinterpret_cast<const s8i __attribute__((address_space(4)))*>(row + 4);      // a: E_I E_Q O_I O_Q A_I A_Q sink present
+                    const s8i db = *reinterpret_cast<const s8i __attribute__((address_space(4)))*>(row + 16);     // b
+                    const int mode_a = row[28];
+                    const int blk = 16 * tb + n16;
+                    // window of block blk: int16 entries [16 blk + 8, 16 blk + 72) of the parent's (biased) odd arm
+                    const int wo = 4 + 8 * blk + 4 * g4;
+                    auto ld16 = [&](int off) { return *reinterpret_cast<const v4i*>(__builtin_assume_aligned(lds + off, 16)); };
+                    auto ld8 = [&](int off) { return *reinterpret_cast<const uint2*>(__builtin_assume_aligned(lds + off, 8)); };
+                    const v4i bI0 = ld16(rd[0] + wo), bI1 = ld16(rd[0] + wo + 16);
+                    const v4i bQ0 = ld16(rd[1] + wo), bQ1 = ld16(rd[1] + wo + 16);
+                    // centre taps e[k - 11], k = 16 blk + 4 g + i: int16 entries 16 blk + 4 g + 21 + i of the even arm that feeds the
+                    // I accumulator (the parent's eI, or its eQ below a lower/upper stage) and of the one feeding Q
+                    const int co = 10 + 8 * blk + 2 * g4;
+                    const uint2 cI01 = ld8(rd[2] + co); const uint32_t cI2 = lds[rd[2] + co + 2];
+                    const uint2 cQ01 = ld8(rd[3] + co); const uint32_t cQ2 = lds[rd[3] + co + 2];
+                    const v4i SI = taps.tile(bI0, bI1, bias), SQ = taps.tile(bQ0, bQ1, bias);
+                    // (S +- (e << 11)) >> 11 == (S >> 11) +- e: |S| < 2^28 for any int16 data
+                    int sI[4], sQ[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { sI[i] = SI[i] >> (HB_SHIFT - 1); sQ[i] = SQ[i] >> (HB_SHIFT - 1); }
+                    const int eI[4] = { (int)cI01.x >> 16, (int)(int16_t)cI01.y, (int)cI01.y >> 16, (int)(int16_t)cI2 };
+                    const int eQ[4] = { (int)cQ01.x >> 16, (int)(int16_t)cQ01.y, (int)cQ01.y >> 16, (int)(int16_t)cQ2 };
+                    const int p = HIST / 2 + 4 * blk + g4;
+                    const long abs0 = chunk * lv.nout + 16 * blk + 4 * g4;
+                    // one stage's outputs: arms of the children (LDS), node streams / channel ends (global memory)
+                    auto emit = [&](const int (&yI)[4], const int (&yQ)[4], const s8i o) {
+                        if (o[0] >= 0) { lds[o[0] + p] = pack_iq(yI[0], yI[2]); lds[o[1] + p] = pack_iq(yQ[0], yQ[2]); }
+                        const uint32_t odI = pack_iq(yI[1], yI[3]), odQ = pack_iq(yQ[1], yQ[3]);
+                        if (o[2] >= 0) { lds[o[2] + p] = odI ^ xm; lds[o[3] + p] = odQ ^ xm; }
+                        if (o[4] >= 0) {                                            // entry 8 blk + 2 g is even: wrap-negated
+                            lds[o[4] + p] = (((0u - odI) & 0xffffu) | (odI & 0xffff0000u)) ^ xm;
+                            lds[o[5] + p] = (((0u - odQ) & 0xffffu) | (odQ & 0xffff0000u)) ^ xm;
+                        }
+                        if (live) {
+                            for (int si = o[6]; si >= 0; ) {
+                                const s8i sr = *reinterpret_cast<const s8i __attribute__((address_space(4)))*>((cint*)reinterpret_cast<const int*>(sinks + si));
+                                const long ptr0 = ((long)sr[1] << 32) | (uint32_t)sr[0];
+                                const long lo = ((long)sr[3] << 32) | (uint32_t)sr[2], hi = ((long)sr[5] << 32) | (uint32_t)sr[4];
+                                const int shift = sr[6];
+                                uint32_t w[4];
+#pragma unroll
+                                for (int i = 0; i < 4; i++)
+                                    w[i] = shift ? pack_iq(div_pow2_trunc((int)(int16_t)yI[i], shift), div_pow2_trunc((int)(int16_t)yQ[i], shift))
+                                                 : pack_iq(yI[i], yQ[i]);
+                                typedef uint32_t __attribute__((address_space(1))) gu32;
+                                gu32* dst = (gu32*)(reinterpret_cast<uint32_t*>(ptr0) + abs0);
+                                const long rel = abs0 - lo, span = hi - lo;
+                                if (rel >= 0 && rel + 4 <= span) { dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2]; dst[3] = w[3]; }
+                                else if (rel > -4 && rel < span) {
+#pragma unroll
+                                    for (int i = 0; i < 4; i++) if (rel + i >= 0 && rel + i < span) dst[i] = w[i];
+                                }
+                                si = sr[7];
+                            }
+                        }
+                    };
+                    if (mode_a == MODE_CEN) {
+                        const int yI[4] = { sI[0] + eI[0], sI[1] + eI[1], sI[2] + eI[2], sI[3] + eI[3] };
+                        const int yQ[4] = { sQ[0] + eQ[0], sQ[1] + eQ[1], sQ[2] + eQ[2], sQ[3] + eQ[3] };
+                        emit(yI, yQ, da);
+                    } else {
+                        // lower half: k even -> (+im, -re), k odd -> (-im, +re); upper half: the negation (inthalfbandfiltereo.h:158-206,
+                        // 357-405; eI / eQ already come from the OTHER component's even arm).  `a` is the lower child when there is
+                        // one, else the upper one; `b` the upper one when both exist.
+                        const bool hasL = mode_a == MODE_INF, hasU = mode_a == MODE_SUP || db[7] != 0;
+                        if (hasL) {
+                            const int yI[4] = { sI[0] + eI[0], sI[1] - eI[1], sI[2] + eI[2], sI[3] - eI[3] };
+                            const int yQ[4] = { sQ[0] - eQ[0], sQ[1] + eQ[1], sQ[2] - eQ[2], sQ[3] + eQ[3] };
+                            emit(yI, yQ, da);
+                        }
+                        if (hasU) {
+                            const int yI[4] = { sI[0] - eI[0], sI[1] + eI[1], sI[2] - eI[2], sI[3] + eI[3] };
+                            const int yQ[4] = { sQ[0] + eQ[0], sQ[1] - eQ[1], sQ[2] + eQ[2], sQ[3] - eQ[3] };
+                            emit(yI, yQ, hasL ? db : da);
+                        }
+                    }
+                }
+                __syncthreads();
+                continue;
             }
             // One job = (table entry, R consecutive outputs).  R = 8 while that still gives every lane a job; narrow levels
             // (few entries, short chunks: the bottom of every subtree) drop to R = 4 or 2 so that the lanes stay busy --
