@@ -90,10 +90,17 @@ struct HbMfmaTaps {
         P3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(p3[1], b1, P3, 0, 0, 0);
         P2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(p2[1], b1, P2, 0, 0, 0);
         if constexpr (P1_STEP2) P1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(p1[1], b1, P1, 0, 0, 0);
+        // S = (P1 << 16) + (P2 << 8) + P3 as a Horner chain of two v_lshl_add_u32 (left alone the compiler makes it two shifts and
+        // an add3: the combine is the largest VALU item of the stage)
         v4i S;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            S[i] = (int)(((uint32_t)P1[i] << 16) + (((uint32_t)P2[i] << 8) + (uint32_t)P3[i]));
+        for (int i = 0; i < 4; i++) {
+            // (the empty asm only stops the re-association; an asm that READ the MFMA results itself would sit outside the
+            // compiler's MFMA -> VALU hazard padding)
+            uint32_t t = ((uint32_t)P1[i] << 8) + (uint32_t)P2[i];
+            asm("" : "+v"(t));
+            S[i] = (int)((t << 8) + (uint32_t)P3[i]);
+        }
         return S;
     }
 };

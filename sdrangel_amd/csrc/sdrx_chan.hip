@@ -119,11 +119,12 @@ struct Group {
     std::vector<TkSubtree> subtrees;
     std::vector<TkNode> nodes;
     std::vector<TkArray> arrays;
+    std::vector<TkMJob> mjobs;    // matrix-core jobs of every MFMA level (tree_kernel.hpp)
     std::vector<SinkInfo> sinks;
     int max_lds_dw = 0;
     bool mfma = true;             // engine this group was planned for
     void* d_static = nullptr;     // subtrees | nodes | arrays
-    TkSubtree* d_subtrees = nullptr; TkNode* d_nodes = nullptr; TkArray* d_arrays = nullptr;
+    TkSubtree* d_subtrees = nullptr; TkNode* d_nodes = nullptr; TkArray* d_arrays = nullptr; TkMJob* d_mjobs = nullptr;
 };
 
 int arm_len(int rel_depth) { return HIST / 2 + (TK_CHUNK >> (rel_depth + 2)); }   // dwords
@@ -217,7 +218,7 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
         g->trie[id].ends.push_back(c);
     }
 
-    g->streams.clear(); g->passes.clear(); g->subtrees.clear(); g->nodes.clear(); g->arrays.clear(); g->sinks.clear();
+    g->streams.clear(); g->passes.clear(); g->subtrees.clear(); g->nodes.clear(); g->arrays.clear(); g->sinks.clear(); g->mjobs.clear();
     g->mfma = engine_mfma();
     { Stream raw; raw.trie_node = 0; raw.depth = 0; raw.pass = 0; g->streams.push_back(std::move(raw)); g->trie[0].stream = 0; }
 
@@ -273,9 +274,8 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
             lv.nout = TK_CHUNK >> rel;
             lv.r_log2 = 3; lv.jobs_log2 = 0;                           // fixed up below once the level's entry count is known
             lv.mfma = level_is_mfma(g->mfma, rel) ? 1 : 0;
-            lv.tpe_log2 = 0; while ((256 << lv.tpe_log2) < lv.nout) lv.tpe_log2++;
+            lv.mjob_base = 0; lv.n_mjobs = 0;
             lv.xm = rel < levels && level_is_mfma(g->mfma, rel + 1) ? HBM_BIAS2 : 0u;
-            lv.pad = 0;
             lv.arr_base = (int)g->arrays.size() - st.array_base;
             int n_entries = 0;
             for (size_t pi = 0; pi < cur.size(); pi++) {
@@ -361,6 +361,7 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
         }
         auto fix = [&](int& v) { if (v >= 0) v = g->arrays[(size_t)(st.array_base + v)].off; };
         st.root_xm = level_is_mfma(g->mfma, 1) ? HBM_BIAS2 : 0u;
+        { const char* e = getenv("SDRX_CHAN_DBG"); st.dbg = e ? atoi(e) : 0; }
         { Arms r = root_arms; for (int q = 0; q < 2; q++) { fix(r.E[q]); fix(r.O[q]); fix(r.A[q]); }
           st.rootE_I = r.E[0]; st.rootE_Q = r.E[1]; st.rootO_I = r.O[0]; st.rootO_Q = r.O[1]; st.rootA_I = r.A[0]; st.rootA_Q = r.A[1]; }
         for (int i = 0; i < rel_nodes; i++) {
@@ -381,6 +382,40 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
         st.n_sinks = (int)g->sinks.size() - st.sink_base;
         st.sink_tab = (st.arr_tab + st.n_arrays + 1) & ~1;                  // 8-byte aligned: read as uint2
         st.lds_dwords = st.sink_tab + st.n_sinks * TK_SINK_DW;
+        {   // matrix-core jobs: LDS byte addresses of every array a job touches, 256 tb outputs into the chunk; 64 dwords of
+            // scratch take the stores to arm arrays a child does not have
+            const int trash = (st.lds_dwords + 3) & ~3;
+            bool any = false;
+            for (int l = 0; l < levels; l++) {
+                TkLevel& lv = st.lv[l];
+                if (!lv.mfma) continue;
+                any = true;
+                lv.mjob_base = (int)g->mjobs.size();
+                const int tpe = lv.nout / 256;
+                for (int e = 0; e < lv.n_nodes; e++) {
+                    const TkNode& nd = g->nodes[(size_t)(st.node_base + lv.node_base + e)];
+                    for (int tb = 0; tb < tpe; tb++) {
+                        TkMJob j; memset(&j, 0, sizeof j);
+                        j.bI = (nd.oddI + 4 + 128 * tb) * 4; j.bQ = (nd.oddQ + 4 + 128 * tb) * 4;
+                        j.cI = (nd.cenI + 10 + 128 * tb) * 4; j.cQ = (nd.cenQ + 10 + 128 * tb) * 4;
+                        j.mode = nd.mode_a == SDRX_MODE_CENTER ? 0 : 1;
+                        j.out0 = 256 * tb;
+                        auto put = [&](TkMOut& m, const TkOut* o) {
+                            auto at = [&](int off) { return (off >= 0 ? off + HIST / 2 + 64 * tb : trash) * 4; };
+                            if (!o) { m.E_I = m.E_Q = m.O_I = m.O_Q = m.A_I = m.A_Q = trash * 4; m.sink = -1; m.flags = 0; return; }
+                            m.E_I = at(o->outE_I); m.E_Q = at(o->outE_Q); m.O_I = at(o->outO_I); m.O_Q = at(o->outO_Q);
+                            m.A_I = at(o->outA_I); m.A_Q = at(o->outA_Q);
+                            m.sink = o->sink; m.flags = (o->outE_I >= 0 ? 1 : 0) | (o->outO_I >= 0 ? 2 : 0) | (o->outA_I >= 0 ? 4 : 0);
+                        };
+                        if (nd.mode_a == SDRX_MODE_UPPER) { put(j.o[0], nullptr); put(j.o[1], &nd.a); }
+                        else { put(j.o[0], &nd.a); put(j.o[1], nd.b.present ? &nd.b : nullptr); }
+                        g->mjobs.push_back(j);
+                    }
+                }
+                lv.n_mjobs = (int)g->mjobs.size() - lv.mjob_base;
+            }
+            if (any) st.lds_dwords = trash + 64;
+        }
         if (st.lds_dwords > 0xffff) { set_error("channel tree does not fit the 16-bit LDS offsets of the array table"); return SDRX_EINVAL; }
         for (int l = 0; l < levels; l++) st.lv[l].in_len = arm_len(l);
         g->max_lds_dw = std::max(g->max_lds_dw, st.lds_dwords);
@@ -401,8 +436,9 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
         }
     }
     const size_t b0 = g->subtrees.size() * sizeof(TkSubtree), b1 = g->nodes.size() * sizeof(TkNode), b2 = g->arrays.size() * sizeof(TkArray);
+    const size_t b3 = g->mjobs.size() * sizeof(TkMJob);
     if (b0 + b1 + b2 > 0) {
-        SDRX_HIP(hipMalloc(&g->d_static, b0 + b1 + b2 + 64));
+        SDRX_HIP(hipMalloc(&g->d_static, b0 + b1 + b2 + b3 + 64));
         char* p = static_cast<char*>(g->d_static);
         g->d_subtrees = reinterpret_cast<TkSubtree*>(p);
         g->d_nodes = reinterpret_cast<TkNode*>(p + b0);
@@ -410,6 +446,8 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
         if (b0) SDRX_HIP(hipMemcpy(g->d_subtrees, g->subtrees.data(), b0, hipMemcpyHostToDevice));
         if (b1) SDRX_HIP(hipMemcpy(g->d_nodes, g->nodes.data(), b1, hipMemcpyHostToDevice));
         if (b2) SDRX_HIP(hipMemcpy(g->d_arrays, g->arrays.data(), b2, hipMemcpyHostToDevice));
+        g->d_mjobs = reinterpret_cast<TkMJob*>(p + b0 + b1 + b2);
+        if (b3) SDRX_HIP(hipMemcpy(g->d_mjobs, g->mjobs.data(), b3, hipMemcpyHostToDevice));
     }
     return SDRX_OK;
 }
@@ -581,10 +619,10 @@ static int feed_group(sdrx_chan_bank* b, Group* g, const uint32_t* d_in, int64_t
         for (int si : ps) lds_bytes = std::max(lds_bytes, (size_t)g->subtrees[(size_t)g->streams[(size_t)si].subtree].lds_dwords * 4);
         if (g->mfma)
             hipLaunchKernelGGL(tree_kernel<true>, dim3((unsigned)max_segs, (unsigned)cnt), dim3(TK_THREADS), lds_bytes, b->stream,
-                               g->d_subtrees, g->d_nodes, g->d_arrays, d_streams + s0, d_sinks);
+                               g->d_subtrees, g->d_nodes, g->d_arrays, d_streams + s0, d_sinks, g->d_mjobs);
         else
             hipLaunchKernelGGL(tree_kernel<false>, dim3((unsigned)max_segs, (unsigned)cnt), dim3(TK_THREADS), lds_bytes, b->stream,
-                               g->d_subtrees, g->d_nodes, g->d_arrays, d_streams + s0, d_sinks);
+                               g->d_subtrees, g->d_nodes, g->d_arrays, d_streams + s0, d_sinks, g->d_mjobs);
         SDRX_HIP(hipGetLastError());
         if (p == 0) {
             snprintf(b->last_name, sizeof b->last_name, g->mfma ? "tree_kernel<mfma>" : "tree_kernel<valu>");

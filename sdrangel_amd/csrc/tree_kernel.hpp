@@ -60,10 +60,25 @@ struct TkLevel {
     int r_log2;                                  // outputs per job: 8, 4 or 2
     int in_len;                                  // dwords of every array this level READS (its parents' arms)
     int mfma;                                    // 1: the level runs on the matrix cores (hb_mfma.hpp): nout >= 256, whole jobs per entry
-    int tpe_log2;                                // jobs per entry = nout / 256 (a job = 16 blocks of 16 outputs, I and Q = two MFMA tiles)
+    int mjob_base, n_mjobs;                      // its jobs in the group's TkMJob table (a job = 16 blocks of 16 outputs of one entry, I and Q = two MFMA tiles)
     uint32_t xm;                                 // XORed into the odd-arm dwords this level PRODUCES: HBM_BIAS2 if the next level is an MFMA level
-    int pad;
 };
+
+// One matrix-core job, everything resolved by the planner to LDS BYTE addresses of the job's first element (the lane adds its
+// share): wave-uniform, fetched with three wide scalar loads.  o[0] / o[1]: a centre stage uses o[0]; a lower/upper pair has the
+// lower child in o[0] and the upper one in o[1] (either may be absent: flags = 0, sink = -1).  Absent arm arrays of a present
+// child point at a scratch slot, so the epilogue has no branch per array.
+struct TkMOut { int E_I, E_Q, O_I, O_Q, A_I, A_Q; int sink; int flags; };     // flags: 1 = even arms, 2 = plain odd arms, 4 = alternating odd arms
+struct TkMJob {
+    int bI, bQ;                 // window entry 0 of block 16 tb of the odd arm feeding I / Q
+    int cI, cQ;                 // dword holding even-arm entry 16 (16 tb) + 20 (centre taps of the job's first block)
+    int mode;                   // 0: centre stage, else lower/upper pair
+    int out0;                   // first output of the job inside the chunk: 256 tb
+    int pad[2];
+    TkMOut o[2];
+    int pad2[8];
+};
+static_assert(sizeof(TkMJob) == 128, "job table layout");
 
 struct TkSubtree {
     int n_levels;
@@ -72,14 +87,15 @@ struct TkSubtree {
     int node_base;              // first node (global index) -- levels index relative to the table
     int n_arrays, array_base;   // all arrays: [root arrays][level-1 arrays][level-2 arrays]...
     int root_arr_cnt;           // the first root_arr_cnt arrays are the root arms
-    int lds_dwords;             // two arm regions + history store + node table copy
+    int lds_dwords;             // two arm regions + history store + node table copy (+ 256 B scratch for the MFMA jobs' absent arms)
     int sink_base, n_sinks;     // this subtree's sinks are one contiguous run of the group's sink table
     int sink_tab;               // LDS dword offset of the copy of that run (TK_SINK_DW dwords each)
     int node_tab;               // LDS dword offset of the node table copy
     int arr_tab;                // LDS dword offset of the array table copy: off | store << 16, one dword per array
     int rootE_I, rootE_Q, rootO_I, rootO_Q, rootA_I, rootA_Q;   // root arms (-1: none)
     uint32_t root_xm;           // XORed into the root odd arms (HBM_BIAS2 if level 1 is an MFMA level)
-    int pad0;
+    int dbg;                    // timing experiments only (SDRX_CHAN_DBG, results are WRONG when set): 1 skip MFMA jobs, 2 skip the
+                                // history walks, 4 skip the root fill, 16 skip the MFMA epilogues
     TkLevel lv[TK_MAX_LEVELS];
 };
 
@@ -122,7 +138,7 @@ template<bool MX>
 __global__ __launch_bounds__(TK_THREADS, 4)
 void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restrict__ nodes,
                  const TkArray* __restrict__ arrays, const TkStream* __restrict__ streams,
-                 const TkSink* __restrict__ sinks)
+                 const TkSink* __restrict__ sinks, const TkMJob* __restrict__ mjobs)
 {
     constexpr int C = TK_CHUNK, NT = TK_THREADS, LPT = C / 4 / NT;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -166,6 +182,7 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     if constexpr (MX) taps.init(lane);
     const uint32_t root_xm = MX ? st.root_xm : 0u;
+    const int dbg = st.dbg;
 
     uint4 pre[LPT];
     auto fetch = [&](long chunk) {
@@ -192,6 +209,7 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
         // ---- stream samples -> root arms
 #pragma unroll
         for (int j = 0; j < LPT; j++) {
+            if (dbg & 4) break;
             const int q = HIST / 2 + j * NT + tid;
             const uint4 v = pre[j];
             const uint32_t oI = __builtin_amdgcn_perm(v.w, v.y, 0x05040100u);
@@ -221,7 +239,7 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                 // last 16 dwords are kept for the next chunk now (this used to be a second dependent LDS round trip behind
                 // the jobs of every level).
                 const int sb = l == 0 ? 0 : st.lv[l - 1].arr_base, sc = l == 0 ? st.root_arr_cnt : st.lv[l - 1].arr_cnt;
-                const int n_restore = lv.arr_cnt * 16, n_all = n_restore + sc * 16;
+                const int n_restore = lv.arr_cnt * 16, n_all = (dbg & 2) ? 0 : n_restore + sc * 16;
                 for (int i = tid; i < n_all; i += NT) {
                     if (i < n_restore) {
                         const uint32_t a = lds[st.arr_tab + lv.arr_base + (i >> 4)];
@@ -237,96 +255,110 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                 // ---- the level on the matrix cores (hb_mfma.hpp).  A job = 16 blocks of 16 consecutive outputs of ONE table entry,
                 // I and Q: two tiles, column n = block 16 tb + n; lane (n, g) ends up with outputs 4g .. 4g+3 of its block for both
                 // components = one packed dword for the even and one for the odd arm of the children.  Each wave takes a contiguous
-                // run of the level's jobs; everything that describes the entry is wave-uniform (scalar loads, scalar branches).
-                typedef const int __attribute__((address_space(4))) cint;
-                const int njobs = lv.n_nodes << lv.tpe_log2;
-                const int per = (njobs + NT / 64 - 1) / (NT / 64);
-                const int t0 = wv * per, t1 = t0 + per < njobs ? t0 + per : njobs;
+                // run of the level's jobs, two at a time: both jobs' loads, then 20 MFMAs, then the epilogues -- one long basic
+                // block (the job descriptors are wave-uniform scalars; absent arm arrays point at a scratch slot).
+                typedef int s8i __attribute__((ext_vector_type(8)));
+                typedef const s8i __attribute__((address_space(4))) cs8;
+                const int per = (lv.n_mjobs + NT / 64 - 1) / (NT / 64);
+                const int t0 = wv * per, t1 = t0 + per < lv.n_mjobs ? t0 + per : lv.n_mjobs;
                 const v4i bias = { Taps::BIAS, Taps::BIAS, Taps::BIAS, Taps::BIAS };
                 const uint32_t xm = lv.xm;
-                for (int tt = t0; tt < t1; tt++) {
-                    const int ent = tt >> lv.tpe_log2, tb = tt & ((1 << lv.tpe_log2) - 1);
-                    // the entry's descriptor: four wide scalar loads issued together (one wait), not one s_load per field
-                    typedef int s4i __attribute__((ext_vector_type(4)));
-                    typedef int s8i __attribute__((ext_vector_type(8)));
-                    cint* row = (cint*)reinterpret_cast<const int*>(nodes + st.node_base + lv.node_base + ent);
-                    const s4i rd = *reinterpret_cast<const s4i __attribute__((address_space(4)))*>(row);          // oddI, oddQ, cenI, cenQ
-                    const s8i da = *reinterpret_cast<const s8i __attribute__((address_space(4)))*>(row + 4);      // a: E_I E_Q O_I O_Q A_I A_Q sink present
-                    const s8i db = *reinterpret_cast<const s8i __attribute__((address_space(4)))*>(row + 16);     // b
-                    const int mode_a = row[28];
-                    const int blk = 16 * tb + n16;
-                    // window of block blk: int16 entries [16 blk + 8, 16 blk + 72) of the parent's (biased) odd arm
-                    const int wo = 4 + 8 * blk + 4 * g4;
-                    auto ld16 = [&](int off) { return *reinterpret_cast<const v4i*>(__builtin_assume_aligned(lds + off, 16)); };
-                    auto ld8 = [&](int off) { return *reinterpret_cast<const uint2*>(__builtin_assume_aligned(lds + off, 8)); };
-                    const v4i bI0 = ld16(rd[0] + wo), bI1 = ld16(rd[0] + wo + 16);
-                    const v4i bQ0 = ld16(rd[1] + wo), bQ1 = ld16(rd[1] + wo + 16);
+                const char* ldsb = reinterpret_cast<const char*>(lds);
+                char* ldsw = reinterpret_cast<char*>(lds);
+                const int wl = 32 * n16 + 16 * g4, cl = 32 * n16 + 8 * g4, pl = 16 * n16 + 4 * g4;      // the lane's byte offsets
+                struct JobIn { v4i bI0, bI1, bQ0, bQ1; uint2 cI01, cQ01; uint32_t cI2, cQ2; };
+                auto load = [&](const s8i h, JobIn& r) {
+                    r.bI0 = *reinterpret_cast<const v4i*>(__builtin_assume_aligned(ldsb + h[0] + wl, 16));
+                    r.bI1 = *reinterpret_cast<const v4i*>(__builtin_assume_aligned(ldsb + h[0] + wl + 64, 16));
+                    r.bQ0 = *reinterpret_cast<const v4i*>(__builtin_assume_aligned(ldsb + h[1] + wl, 16));
+                    r.bQ1 = *reinterpret_cast<const v4i*>(__builtin_assume_aligned(ldsb + h[1] + wl + 64, 16));
                     // centre taps e[k - 11], k = 16 blk + 4 g + i: int16 entries 16 blk + 4 g + 21 + i of the even arm that feeds the
                     // I accumulator (the parent's eI, or its eQ below a lower/upper stage) and of the one feeding Q
-                    const int co = 10 + 8 * blk + 2 * g4;
-                    const uint2 cI01 = ld8(rd[2] + co); const uint32_t cI2 = lds[rd[2] + co + 2];
-                    const uint2 cQ01 = ld8(rd[3] + co); const uint32_t cQ2 = lds[rd[3] + co + 2];
-                    const v4i SI = taps.tile(bI0, bI1, bias), SQ = taps.tile(bQ0, bQ1, bias);
-                    // (S +- (e << 11)) >> 11 == (S >> 11) +- e: |S| < 2^28 for any int16 data
-                    int sI[4], sQ[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { sI[i] = SI[i] >> (HB_SHIFT - 1); sQ[i] = SQ[i] >> (HB_SHIFT - 1); }
-                    const int eI[4] = { (int)cI01.x >> 16, (int)(int16_t)cI01.y, (int)cI01.y >> 16, (int)(int16_t)cI2 };
-                    const int eQ[4] = { (int)cQ01.x >> 16, (int)(int16_t)cQ01.y, (int)cQ01.y >> 16, (int)(int16_t)cQ2 };
-                    const int p = HIST / 2 + 4 * blk + g4;
-                    const long abs0 = chunk * lv.nout + 16 * blk + 4 * g4;
-                    // one stage's outputs: arms of the children (LDS), node streams / channel ends (global memory)
-                    auto emit = [&](const int (&yI)[4], const int (&yQ)[4], const s8i o) {
-                        if (o[0] >= 0) { lds[o[0] + p] = pack_iq(yI[0], yI[2]); lds[o[1] + p] = pack_iq(yQ[0], yQ[2]); }
-                        const uint32_t odI = pack_iq(yI[1], yI[3]), odQ = pack_iq(yQ[1], yQ[3]);
-                        if (o[2] >= 0) { lds[o[2] + p] = odI ^ xm; lds[o[3] + p] = odQ ^ xm; }
-                        if (o[4] >= 0) {                                            // entry 8 blk + 2 g is even: wrap-negated
-                            lds[o[4] + p] = (((0u - odI) & 0xffffu) | (odI & 0xffff0000u)) ^ xm;
-                            lds[o[5] + p] = (((0u - odQ) & 0xffffu) | (odQ & 0xffff0000u)) ^ xm;
+                    r.cI01 = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(ldsb + h[2] + cl, 8));
+                    r.cI2 = *reinterpret_cast<const uint32_t*>(ldsb + h[2] + cl + 8);
+                    r.cQ01 = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(ldsb + h[3] + cl, 8));
+                    r.cQ2 = *reinterpret_cast<const uint32_t*>(ldsb + h[3] + cl + 8);
+                };
+                // one stage's outputs, PACKED: eI = (y0, y2), oI = (y1, y3) of the I component, eQ / oQ of Q (int16 halves, wrapped:
+                // Sample storage, inthalfbandfiltereo.h:828-829): arms of the children (LDS), node streams / channel ends (global memory)
+                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                auto padd = [](uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b))); };
+                auto psub = [](uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b))); };
+                auto emit = [&](const uint32_t eI, const uint32_t oI, const uint32_t eQ, const uint32_t oQ, const s8i o, const long abs0) {
+                    if (o[7]) {
+                        *reinterpret_cast<uint32_t*>(ldsw + o[0] + pl) = eI;
+                        *reinterpret_cast<uint32_t*>(ldsw + o[1] + pl) = eQ;
+                        if (o[7] & 2) {
+                            *reinterpret_cast<uint32_t*>(ldsw + o[2] + pl) = oI ^ xm;
+                            *reinterpret_cast<uint32_t*>(ldsw + o[3] + pl) = oQ ^ xm;
                         }
-                        if (live) {
-                            for (int si = o[6]; si >= 0; ) {
-                                const s8i sr = *reinterpret_cast<const s8i __attribute__((address_space(4)))*>((cint*)reinterpret_cast<const int*>(sinks + si));
-                                const long ptr0 = ((long)sr[1] << 32) | (uint32_t)sr[0];
-                                const long lo = ((long)sr[3] << 32) | (uint32_t)sr[2], hi = ((long)sr[5] << 32) | (uint32_t)sr[4];
-                                const int shift = sr[6];
-                                uint32_t w[4];
-#pragma unroll
-                                for (int i = 0; i < 4; i++)
-                                    w[i] = shift ? pack_iq(div_pow2_trunc((int)(int16_t)yI[i], shift), div_pow2_trunc((int)(int16_t)yQ[i], shift))
-                                                 : pack_iq(yI[i], yQ[i]);
-                                typedef uint32_t __attribute__((address_space(1))) gu32;
-                                gu32* dst = (gu32*)(reinterpret_cast<uint32_t*>(ptr0) + abs0);
-                                const long rel = abs0 - lo, span = hi - lo;
-                                if (rel >= 0 && rel + 4 <= span) { dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2]; dst[3] = w[3]; }
-                                else if (rel > -4 && rel < span) {
-#pragma unroll
-                                    for (int i = 0; i < 4; i++) if (rel + i >= 0 && rel + i < span) dst[i] = w[i];
-                                }
-                                si = sr[7];
-                            }
-                        }
-                    };
-                    if (mode_a == MODE_CEN) {
-                        const int yI[4] = { sI[0] + eI[0], sI[1] + eI[1], sI[2] + eI[2], sI[3] + eI[3] };
-                        const int yQ[4] = { sQ[0] + eQ[0], sQ[1] + eQ[1], sQ[2] + eQ[2], sQ[3] + eQ[3] };
-                        emit(yI, yQ, da);
-                    } else {
-                        // lower half: k even -> (+im, -re), k odd -> (-im, +re); upper half: the negation (inthalfbandfiltereo.h:158-206,
-                        // 357-405; eI / eQ already come from the OTHER component's even arm).  `a` is the lower child when there is
-                        // one, else the upper one; `b` the upper one when both exist.
-                        const bool hasL = mode_a == MODE_INF, hasU = mode_a == MODE_SUP || db[7] != 0;
-                        if (hasL) {
-                            const int yI[4] = { sI[0] + eI[0], sI[1] - eI[1], sI[2] + eI[2], sI[3] - eI[3] };
-                            const int yQ[4] = { sQ[0] - eQ[0], sQ[1] + eQ[1], sQ[2] - eQ[2], sQ[3] + eQ[3] };
-                            emit(yI, yQ, da);
-                        }
-                        if (hasU) {
-                            const int yI[4] = { sI[0] - eI[0], sI[1] + eI[1], sI[2] - eI[2], sI[3] + eI[3] };
-                            const int yQ[4] = { sQ[0] + eQ[0], sQ[1] - eQ[1], sQ[2] + eQ[2], sQ[3] - eQ[3] };
-                            emit(yI, yQ, hasL ? db : da);
+                        if (o[7] & 4) {
+                            // alternating-sign copy for lower/upper children: entry 8 blk + 2 g is even -> wrap-negated (one packed
+                            // multiply by (-1, +1): the low half wraps like (FixReal) -x)
+                            const us2 sg = { 0xffffu, 1u };
+                            *reinterpret_cast<uint32_t*>(ldsw + o[4] + pl) = __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, oI) * sg)) ^ xm;
+                            *reinterpret_cast<uint32_t*>(ldsw + o[5] + pl) = __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, oQ) * sg)) ^ xm;
                         }
                     }
+                    if (live) {
+                        for (int si = o[6]; si >= 0; ) {
+                            const s8i sr = *(cs8*)reinterpret_cast<const int*>(sinks + si);
+                            const long ptr0 = ((long)sr[1] << 32) | (uint32_t)sr[0];
+                            const long lo = ((long)sr[3] << 32) | (uint32_t)sr[2], hi = ((long)sr[5] << 32) | (uint32_t)sr[4];
+                            const int shift = sr[6];
+                            uint32_t w[4];
+                            if (shift) {
+                                w[0] = pack_iq(div_pow2_trunc((int)(int16_t)eI, shift), div_pow2_trunc((int)(int16_t)eQ, shift));
+                                w[1] = pack_iq(div_pow2_trunc((int)(int16_t)oI, shift), div_pow2_trunc((int)(int16_t)oQ, shift));
+                                w[2] = pack_iq(div_pow2_trunc((int)eI >> 16, shift), div_pow2_trunc((int)eQ >> 16, shift));
+                                w[3] = pack_iq(div_pow2_trunc((int)oI >> 16, shift), div_pow2_trunc((int)oQ >> 16, shift));
+                            } else {
+                                w[0] = __builtin_amdgcn_perm(eQ, eI, 0x05040100u); w[1] = __builtin_amdgcn_perm(oQ, oI, 0x05040100u);
+                                w[2] = __builtin_amdgcn_perm(eQ, eI, 0x07060302u); w[3] = __builtin_amdgcn_perm(oQ, oI, 0x07060302u);
+                            }
+                            typedef uint32_t __attribute__((address_space(1))) gu32;
+                            gu32* dst = (gu32*)(reinterpret_cast<uint32_t*>(ptr0) + abs0);
+                            const long rel = abs0 - lo, span = hi - lo;
+                            if (rel >= 0 && rel + 4 <= span) { dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2]; dst[3] = w[3]; }
+                            else if (rel > -4 && rel < span) {
+#pragma unroll
+                                for (int i = 0; i < 4; i++) if (rel + i >= 0 && rel + i < span) dst[i] = w[i];
+                            }
+                            si = sr[7];
+                        }
+                    }
+                };
+                auto finish = [&](const JobIn& r, const v4i SI, const v4i SQ, const s8i h, const s8i oa, const s8i ob) {
+                    // (S +- (e << 11)) >> 11 == (S >> 11) +- e (|S| < 2^28 for any int16 data), and the int16 store keeps the sum
+                    // modulo 2^16: pack the shifted sums and the centre taps first, then add / subtract two outputs per instruction
+                    const uint32_t sI02 = pack_iq(SI[0] >> (HB_SHIFT - 1), SI[2] >> (HB_SHIFT - 1)), sI13 = pack_iq(SI[1] >> (HB_SHIFT - 1), SI[3] >> (HB_SHIFT - 1));
+                    const uint32_t sQ02 = pack_iq(SQ[0] >> (HB_SHIFT - 1), SQ[2] >> (HB_SHIFT - 1)), sQ13 = pack_iq(SQ[1] >> (HB_SHIFT - 1), SQ[3] >> (HB_SHIFT - 1));
+                    // centre taps e0..e3 = int16 entries 1, 2, 3, 4 of the three dwords read: (e0, e2) and (e1, e3)
+                    const uint32_t cI02 = __builtin_amdgcn_perm(r.cI01.y, r.cI01.x, 0x07060302u), cI13 = __builtin_amdgcn_perm(r.cI2, r.cI01.y, 0x05040100u);
+                    const uint32_t cQ02 = __builtin_amdgcn_perm(r.cQ01.y, r.cQ01.x, 0x07060302u), cQ13 = __builtin_amdgcn_perm(r.cQ2, r.cQ01.y, 0x05040100u);
+                    const long abs0 = chunk * lv.nout + h[5] + 16 * n16 + 4 * g4;
+                    if (h[4] == 0) {
+                        emit(padd(sI02, cI02), padd(sI13, cI13), padd(sQ02, cQ02), padd(sQ13, cQ13), oa, abs0);
+                    } else {
+                        // lower half: k even -> (+im, -re), k odd -> (-im, +re); upper half: the negation (inthalfbandfiltereo.h:158-206,
+                        // 357-405; cI / cQ already come from the OTHER component's even arm)
+                        if (oa[7] | (oa[6] >= 0)) emit(padd(sI02, cI02), psub(sI13, cI13), psub(sQ02, cQ02), padd(sQ13, cQ13), oa, abs0);
+                        if (ob[7] | (ob[6] >= 0)) emit(psub(sI02, cI02), padd(sI13, cI13), padd(sQ02, cQ02), psub(sQ13, cQ13), ob, abs0);
+                    }
+                };
+                for (int tt = t0; tt < t1; tt += 2) {
+                    if (dbg & 1) break;
+                    const bool two = tt + 1 < t1;
+                    cs8* d0 = (cs8*)reinterpret_cast<const int*>(mjobs + lv.mjob_base + tt);
+                    cs8* d1 = (cs8*)reinterpret_cast<const int*>(mjobs + lv.mjob_base + (two ? tt + 1 : tt));
+                    const s8i h0 = d0[0], a0 = d0[1], b0 = d0[2], h1 = d1[0], a1 = d1[1], b1 = d1[2];
+                    JobIn r0, r1;
+                    load(h0, r0); load(h1, r1);
+                    const v4i SI0 = taps.tile(r0.bI0, r0.bI1, bias), SQ0 = taps.tile(r0.bQ0, r0.bQ1, bias);
+                    const v4i SI1 = taps.tile(r1.bI0, r1.bI1, bias), SQ1 = taps.tile(r1.bQ0, r1.bQ1, bias);
+                    if ((dbg & 16) && (SI0[0] ^ SQ0[1] ^ SI1[2] ^ SQ1[3]) != 0x12345678) continue;
+                    finish(r0, SI0, SQ0, h0, a0, b0);
+                    if (two) finish(r1, SI1, SQ1, h1, a1, b1);
                 }
                 __syncthreads();
                 continue;

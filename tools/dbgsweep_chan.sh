@@ -1,0 +1,7 @@
+#!/bin/bash
+# timing by elimination for the bank's tree kernel (SDRX_CHAN_DBG bits: tree_kernel.hpp; results are wrong when set)
+mkdir -p gpurun_out/r3a
+for d in ${@:-0 1 16}; do
+  SDRX_CHAN_DBG=$d timeout -k 10 120 python bench.py --workload chan32 --steps 5 --no-cpu 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('dbg $d', d['ms_per_step'], d['roofline']['kernel_ms'])"
+done
