@@ -346,19 +346,27 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                         if (ob[7] | (ob[6] >= 0)) emit(psub(sI02, cI02), padd(sI13, cI13), padd(sQ02, cQ02), psub(sQ13, cQ13), ob, abs0);
                     }
                 };
-                for (int tt = t0; tt < t1; tt += 2) {
-                    if (dbg & 1) break;
-                    const bool two = tt + 1 < t1;
+                int tt = (dbg & 1) ? t1 : t0;
+                for (; tt + 1 < t1; tt += 2) {
                     cs8* d0 = (cs8*)reinterpret_cast<const int*>(mjobs + lv.mjob_base + tt);
-                    cs8* d1 = (cs8*)reinterpret_cast<const int*>(mjobs + lv.mjob_base + (two ? tt + 1 : tt));
+                    cs8* d1 = (cs8*)reinterpret_cast<const int*>(mjobs + lv.mjob_base + tt + 1);
                     const s8i h0 = d0[0], a0 = d0[1], b0 = d0[2], h1 = d1[0], a1 = d1[1], b1 = d1[2];
                     JobIn r0, r1;
                     load(h0, r0); load(h1, r1);
+                    __builtin_amdgcn_sched_barrier(0);                             // every LDS read of the pair is in flight before the first MFMA
                     const v4i SI0 = taps.tile(r0.bI0, r0.bI1, bias), SQ0 = taps.tile(r0.bQ0, r0.bQ1, bias);
                     const v4i SI1 = taps.tile(r1.bI0, r1.bI1, bias), SQ1 = taps.tile(r1.bQ0, r1.bQ1, bias);
                     if ((dbg & 16) && (SI0[0] ^ SQ0[1] ^ SI1[2] ^ SQ1[3]) != 0x12345678) continue;
                     finish(r0, SI0, SQ0, h0, a0, b0);
-                    if (two) finish(r1, SI1, SQ1, h1, a1, b1);
+                    finish(r1, SI1, SQ1, h1, a1, b1);
+                }
+                if (tt < t1) {                                                     // odd job count: the last one on its own
+                    cs8* d0 = (cs8*)reinterpret_cast<const int*>(mjobs + lv.mjob_base + tt);
+                    const s8i h0 = d0[0], a0 = d0[1], b0 = d0[2];
+                    JobIn r0;
+                    load(h0, r0);
+                    const v4i SI0 = taps.tile(r0.bI0, r0.bI1, bias), SQ0 = taps.tile(r0.bQ0, r0.bQ1, bias);
+                    if (!((dbg & 16) && (SI0[0] ^ SQ0[1]) != 0x12345678)) finish(r0, SI0, SQ0, h0, a0, b0);
                 }
                 __syncthreads();
                 continue;

@@ -14,7 +14,7 @@ for name in ("p1", "p2", "p3", "p4"):
             k = r["Kernel_Name"]
             if "sdrx" not in k or "stream_sum" in k:
                 continue
-            short = k.split("sdrx::")[-1].split("(")[0][:40]
+            short = k.split("(")[0].split("sdrx::")[-1][:40]
             if "hist" in short:
                 pos.clear(); continue
             d = r["Dispatch_Id"]
@@ -22,8 +22,11 @@ for name in ("p1", "p2", "p3", "p4"):
                 seen[d] = pos[short]; pos[short] += 1
                 dur[(short, seen[d])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
             acc[(short, seen[d], r["Counter_Name"])].append(float(r["Counter_Value"]))
+import os
+ONLY = os.environ.get("PMC_ONLY", "tree_kernel,decim_fast,decim_chain").split(",")
 last = None
 for k, v in sorted(acc.items()):
+    if not any(o in k[0] for o in ONLY) or k[1] > 2: continue
     if (k[0], k[1]) != last:
         d = dur[(k[0], k[1])]
         print("--- %s  launch #%d of a step: %d samples, %.1f us under --pmc" % (k[0], k[1], len(d), sum(d) / len(d))); last = (k[0], k[1])
