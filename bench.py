@@ -359,8 +359,12 @@ def main():
                 B = int(t.item()); x = None; torch.cuda.empty_cache()
         elif not ok:
             B //= 4
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    torch.cuda.synchronize(dev)                 # the library's streams are not ordered against torch's default stream (handle 0 = "own stream")
+    # ONE explicit stream for every handle of the step (the decimator and the bank run back to back on it, so a kernel trace of the
+    # step adds up to ms_per_step).  Not torch's current stream: that is the null stream, whose handle 0 the library reads as "use the
+    # handle's own stream" -- in round 2 the two halves therefore ran on two unordered streams and overlapped in the profile.
+    tstream = torch.cuda.Stream(device=dev)
+    stream = tstream.cuda_stream
+    torch.cuda.synchronize(dev)                 # inputs were produced on torch's default stream
 
     S = max(1, args.streams_per_gpu)
     timed_handles = {}                          # name -> (handle, algorithmic bytes per sample, samples per step)
@@ -450,6 +454,12 @@ def main():
     sync = (lambda: (be.sync(), torch.cuda.synchronize(dev))) if be is not None else (lambda: torch.cuda.synchronize(dev))
     sync()
     elapsed = shard.timed_region(step, args.steps, 0, sync, dist=dist, device=red_dev)
+    # median of >= 10 individually timed steps (each bracketed by a device synchronisation) next to the mean above
+    singles = []
+    for _ in range(max(10, args.steps)):
+        t0 = time.perf_counter(); step(); sync(); singles.append(time.perf_counter() - t0)
+    singles.sort()
+    ms_median = 1e3 * (singles[len(singles) // 2] if len(singles) % 2 else 0.5 * (singles[len(singles) // 2 - 1] + singles[len(singles) // 2]))
 
     # per-kernel durations: HIP events recorded by the library on the launch stream (sdrx_*_get_timing).  With two
     # different kernels queued back to back the start event of the second is stamped when the command processor reaches
@@ -478,7 +488,8 @@ def main():
         e = {"kernel": ll["kernel"] + (" (all passes of a feed)" if "tree" in ll["kernel"] else ""), "kernel_ms": round(per_feed, 4),
              "launches": k_n, "algorithmic_bytes_per_sample": round(bps, 4), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
              "grid": ll["grid"], "block": ll["block"], "lds_bytes": ll["lds_bytes"]}
-        if d2:
+        eng = os.environ.get("SDRX_CHAN_ENGINE" if "tree" in ll["kernel"] else "SDRX_DECIM_ENGINE", "mfma")
+        if d2 and eng == "valu":                              # the dot2 issue ceiling only binds the VALU engine
             e["dot2_per_sample"] = round(d2, 2)
             e["valu_ceiling_frac"] = round(DOT2_PER_S / d2 * bps / 1e9 / HBM_PEAK_GBS, 4)
         tr, src = load_traffic(ll["kernel"], B, name)
@@ -502,23 +513,79 @@ def main():
         ms128, _n = b128.get_timing(); b128.set_timing(False)
         bps128, d2_128 = bank_figures(b128, 128)
         also["chan128"] = {"workload": f"cfg5 per GPU: DownChannelizer bank, 128 channels x 48 kS/s from one 61.44 MS/s-shaped stream per GPU, {nb} samples per feed",
-                           "value": round(n_gpus * 5 * nb / el128 / 1e6, 1), "unit": "MS/s", "n_gpus": n_gpus, "kernel": "tree_kernel (all passes of a feed)",
+                           "value": round(n_gpus * 5 * nb / el128 / 1e6, 1), "unit": "MS/s", "n_gpus": n_gpus, "kernel": b128.last_launch()["kernel"] + " (all passes of a feed)",
                            "kernel_ms": round(ms128 / 5, 4), "algorithmic_bytes_per_sample": round(bps128, 4),
-                           "roofline_frac": round(bps128 * nb / (ms128 / 5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                           "valu_ceiling_frac": round(DOT2_PER_S / d2_128 * bps128 / 1e9 / HBM_PEAK_GBS, 4)}
+                           "roofline_frac": round(bps128 * nb / (ms128 / 5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         del b128
+
+    if wl == "headline" and not args.no_also and n_gpus == 1:
+        # BASELINE cfg 2 and cfg 3 at the configs' OWN sizes: a 10 M-sample block of the 10 MS/s stream through decimate64_cen,
+        # and one second (61.44 M samples) of the LimeSDR-shaped stream through the 32-channel bank; the headline runs both at 1 Gi samples.
+        def sized(name, make, n, bps, reps=20):
+            hh, fn = make(n)
+            for _ in range(3):
+                fn()
+            sync()
+            hh.set_timing(True)
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter(); fn(); sync(); ts.append(time.perf_counter() - t0)
+            k_ms, _n = hh.get_timing(); hh.set_timing(False)
+            ts.sort()
+            also[name] = {"samples_per_step": n, "kernel_ms": round(k_ms / reps, 4), "kernel": hh.last_launch()["kernel"],
+                          "value": round(n / (k_ms / reps * 1e-3) / 1e6, 1), "unit": "MS/s (device-resident, kernel time)",
+                          "step_ms_median_host_clock": round(1e3 * ts[len(ts) // 2], 4),
+                          "frac": round(bps * n / (k_ms / reps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        def mk_d(n):
+            hh = sa.Decimators(6, sa.FC_CEN, 12, device=dev.index); hh.set_stream(stream)
+            oo = torch.empty(2 * (n >> 6) + 64, dtype=torch.int16, device=dev)
+            return hh, (lambda: hh.decimate_dev(x.data_ptr(), 2 * (n & ~63), oo.data_ptr()))
+        def mk_b(n):
+            bb, _f = make_bank(32, "chan32")
+            def fn():
+                bb.feed_dev(x.data_ptr(), n)
+                for c in range(32):
+                    bb.skip(c)
+            return bb, fn
+        if B >= 61_440_000:
+            sized("cfg2_10M", mk_d, 10_000_000, 4.0 + 4.0 / 64)
+            sized("cfg3_61M44", mk_b, 61_440_000, per_kernel["chan32"]["algorithmic_bytes_per_sample"], reps=10)
+        # end to end INCLUDING the host link: 1 Mi-sample blocks written into the decimator's pinned ring, H2D + kernel + D2H
+        # overlapped (sdrx_decim_ring_*); PCIe-bound, reported for completeness, never `value`
+        try:
+            import numpy as np
+            nblk, slots = 1 << 20, 8
+            hr = sa.Decimators(6, sa.FC_CEN, 12, device=dev.index)
+            hr.ring_create(2 * nblk, slots, 1)
+            def run(k):
+                inflight = 0
+                for _ in range(k):
+                    if inflight == slots - 1:
+                        hr.ring_retire(); inflight -= 1
+                    hr.ring_acquire(); hr.ring_submit(2 * nblk); inflight += 1
+                while inflight:
+                    hr.ring_retire(); inflight -= 1
+            run(2 * slots)
+            t0 = time.perf_counter(); run(128); dt = (time.perf_counter() - t0) / 128
+            also["host_ring"] = {"workload": "decimate64_cen from pinned host blocks (sdrx_decim_ring_*): H2D + kernel + D2H per 1 Mi-sample block, 8 slots",
+                                 "value": round(nblk / dt / 1e6, 1), "unit": "MS/s end to end", "GBps_over_host_link": round(4 * nblk / dt / 1e9, 2)}
+            del hr
+        except Exception as ex:                                    # the ring is optional equipment of the line
+            also["host_ring"] = {"error": str(ex)}
 
     if rank == 0:
         value = n_gpus * args.steps * B / elapsed / 1e6
         ms_step = elapsed / args.steps * 1e3
         dom = max(per_kernel.values(), key=lambda e: e["kernel_ms"])
         low = min(per_kernel.values(), key=lambda e: e["frac"])
-        roof = {"bound": "valu" if wl != "fi64" else "lds+valu", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        engine = {"decim": os.environ.get("SDRX_DECIM_ENGINE", "mfma"), "chan": os.environ.get("SDRX_CHAN_ENGINE", "mfma")}
+        roof = {"bound": "valu" if wl != "fi64" else "lds+valu", "engine": engine, "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": low["frac"], "traffic": dom["traffic"], "traffic_source": dom["traffic_source"],
                 "kernel": dom["kernel"], "kernel_ms": dom["kernel_ms"], "launches": dom["launches"],
                 "algorithmic_bytes_per_sample": dom["algorithmic_bytes_per_sample"],
                 "grid": dom["grid"], "block": dom["block"], "lds_bytes": dom["lds_bytes"],
-                "bound_evidence": "profiles/: SQ counters (VALU issue + power-limited clock), not HBM",
+                "bound_evidence": "profiles/r03_*: the half-band FIRs run on the matrix cores (i8 MFMA, 16-20 % busy); what is left is the VALU "
+                                  "epilogue (limb recombination, centre tap, packing), LDS traffic and wave latency -- not HBM",
                 "per_kernel": per_kernel}
         if "valu_ceiling_frac" in dom:
             roof["valu_ceiling_frac"] = dom["valu_ceiling_frac"]
@@ -538,7 +605,7 @@ def main():
         line = {
             "metric": METRIC,
             "value": round(value, 1), "unit": "MS/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_step, 4), "ms_per_step_median": round(ms_median, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if wl == "fi64" else "int32", "data": "synthetic",
             "config": {"workload": workload, "streams": n_gpus * (S if wl in ("headline", "decim64") else 1), "streams_per_gpu": S if wl in ("headline", "decim64") else 1,
                        "parallelism": f"{n_gpus} GPU(s), one independent 61.44 MS/s-shaped stream set per GPU, no collective"

@@ -20,6 +20,7 @@
 // chunks.  With both outputs < 2^15 the static bounds also make v_mad_i32_i24 exact in stages 4-6.
 #pragma once
 #include "hb_common.hpp"
+#include "hb_mfma.hpp"
 #include "decim_kernel.hpp"
 
 namespace sdrx {
@@ -224,8 +225,11 @@ __host__ __device__ constexpr int df_lds_dwords(int L, int S = DF_SUB) { return 
 // sub-chunks per segment).  NW = 4: the same lane work on sub-chunks of 4096 samples with a real barrier behind every stage and ONE
 // warm-up sub-chunk per segment -- a quarter of the warm-up per wave, for calls too short to give every SIMD several
 // single-wave segments of a useful length (the host picks, sdrx_decim.hip).
-template<int L, int FC, int PRE, bool U8, int NW>
-__global__ __launch_bounds__(64 * NW)
+// MX = true (the default engine): the stages that read packed int16 arms (1..3) evaluate their odd-arm FIR on the matrix
+// cores (hb_mfma.hpp: v_mfma_i32_16x16x64_i8, exact int32 sums) instead of v_dot2c; same LDS layout, same overflow guard,
+// same int32 tail stages.  The odd arms those stages read carry 0x0080 XORed into every int16 (the primitive's byte bias).
+template<int L, int FC, int PRE, bool U8, int NW, bool MX>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MX && NW == 1 ? 3 : 1)))
 void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
 {
     typedef typename Quad<U8>::T QT;
@@ -246,9 +250,26 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
     const long n_in4 = n_in >> 2, n_out = n_in >> L;
 
     for (int i = lane; i < df_lds_dwords(L, S); i += NT) lds[i] = 0;
+    constexpr int MXS = MX ? (L < 3 ? L : 3) : 0;             // stages 1..MXS run on the matrix cores
+    if constexpr (MX) {
+        __syncthreads();
+        static_for<1, MXS + 1>([&](auto sc) {                  // a zero sample of a biased odd arm is 0x0080
+            constexpr int s = decltype(sc)::value;
+            for (int i = lane; i < 2 * df_arr(s, S); i += NT) lds[df_off(s, S) + i] = HBM_BIAS2;
+        });
+    }
 
     DfCoef ctab_cen, ctab_rot;
-    if constexpr (DF_SGPR_COEF) { df_coef_fill<64, MODE_CEN>(ctab_cen); df_coef_fill<64, MODE_INF>(ctab_rot); }
+    if constexpr (DF_SGPR_COEF && !MX) { df_coef_fill<64, MODE_CEN>(ctab_cen); df_coef_fill<64, MODE_INF>(ctab_rot); }
+    // matrix-core operands: plain taps for centre stages, alternating-sign taps for inf/sup stages (the rotation of the odd arm
+    // folded into the taps: exact modulo 2^32).  Only the sets the chain's first three stages use are built.
+    constexpr bool NEED_CEN = MX && (dc_mode(L, FC, 1) == MODE_CEN || (MXS >= 2 && dc_mode(L, FC, 2) == MODE_CEN) || (MXS >= 3 && dc_mode(L, FC, 3) == MODE_CEN));
+    constexpr bool NEED_ROT = MX && (dc_mode(L, FC, 1) != MODE_CEN || (MXS >= 2 && dc_mode(L, FC, 2) != MODE_CEN) || (MXS >= 3 && dc_mode(L, FC, 3) != MODE_CEN));
+    HbMfmaTaps<64, false> taps_cen; HbMfmaTaps<64, true> taps_rot;
+    const int wl = lane & 63, n16 = wl & 15, g4 = wl >> 4, comp = n16 >> 3, bn = n16 & 7;
+    const int wv = MX ? __builtin_amdgcn_readfirstlane(lane >> 6) : 0;
+    if constexpr (NEED_CEN) taps_cen.init(wl);
+    if constexpr (NEED_ROT) taps_rot.init(wl);
 
     QT pre[LPT];
     // A sub-chunk is either wholly history (sub < 0) or wholly input: the source is chosen with a wave-uniform (scalar)
@@ -277,6 +298,7 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
             for (int j = 0; j < LPT; j++) {
                 const int q = HIST / 2 + j * NT + lane;
                 Quad<U8>::split(pre[j], in_shift, eI[q], eQ[q], oI[q], oQ[q]);
+                if constexpr (MX) { oI[q] ^= HBM_BIAS2; oQ[q] ^= HBM_BIAS2; }
             }
         }
         if (sub + 1 < last) fetch(sub + 1);
@@ -289,7 +311,81 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
             constexpr int NOUT = S >> s;
             const uint32_t* iI = lds + df_off(s, S), *iQ = iI + df_arr(s, S), *jI = iQ + df_arr(s, S), *jQ = jI + df_arr(s, S);   // oI,oQ,eI,eQ
             uint32_t* nI = lds + df_off(s + 1, S);                // next stage: oI, oQ, eI, eQ
-            if constexpr (s <= 3) {
+            if constexpr (MX && s <= 3) {
+                // ---- the stage on the matrix cores.  A tile = 8 blocks of 16 consecutive outputs of I (columns 0..7) and of Q
+                // (columns 8..15); lane (n, g) ends up with outputs 4g .. 4g+3 of block 8 t + (n & 7) of component n >> 3.
+                constexpr int SHL = (s == 1 ? PRE : 0);
+                constexpr int TPW = 8 >> s;                                // tiles per wave and sub-chunk: 4, 2, 1
+                constexpr int arr = df_arr(s, S), arr2 = df_arr(s + 1, S);
+                constexpr bool NEXT16 = s < L && s + 1 <= 3;              // the outputs are re-read as packed int16 (by an MFMA stage)
+                const int ec = MODE == MODE_CEN ? comp : 1 - comp;         // inf/sup: the centre tap comes from the other component
+                // sign of the centre tap for even / odd outputs: inf: k even -> (+im, -re), k odd -> (-im, +re); sup: negated
+                const int m_even = MODE == MODE_CEN ? 2048 : ((comp == 0) == (MODE == MODE_INF) ? 2048 : -2048);
+                const int m_odd = MODE == MODE_CEN ? 2048 : -m_even;
+                const uint32_t* ob = iI + comp * arr + 8 * bn + 4 * g4;    // window entry 0 of block bn: int16 index 16 blk
+                const uint32_t* eb = jI + ec * arr + 8 * bn + 2 * g4 + 8;  // centre taps e[k - 15]: int16 entries 16 blk + 4 g + 17 + i
+                constexpr int BIASV = MODE == MODE_CEN ? HbMfmaTaps<64, false>::BIAS : HbMfmaTaps<64, true>::BIAS;
+                const v4i bias = { BIASV, BIASV, BIASV, BIASV };
+                // every load of the stage's tiles first, then the MFMAs, then the epilogues: the stores of one tile must not sit
+                // between the loads of the next (same LDS array as far as the compiler can tell)
+                // (two tiles at a time: four in flight cost 160 VGPRs and a wave per SIMD)
+                constexpr int TG = TPW < 2 ? TPW : 2;
+                static_for<0, TPW / TG>([&](auto gc) {
+                constexpr int g0 = decltype(gc)::value * TG;
+                v4i b0[TG], b1[TG], S4[TG]; uint2 c01[TG]; uint32_t c2[TG];
+                static_for<0, TG>([&](auto tc) {
+                    constexpr int tt = decltype(tc)::value;
+                    const int t = wv * TPW + g0 + tt;
+                    b0[tt] = *reinterpret_cast<const v4i*>(__builtin_assume_aligned(ob + 64 * t, 16));
+                    b1[tt] = *reinterpret_cast<const v4i*>(__builtin_assume_aligned(ob + 64 * t + 16, 16));
+                    c01[tt] = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(eb + 64 * t, 8));
+                    c2[tt] = eb[64 * t + 2];
+                });
+                static_for<0, TG>([&](auto tc) {
+                    constexpr int tt = decltype(tc)::value;
+                    if constexpr (MODE == MODE_CEN) S4[tt] = taps_cen.tile(b0[tt], b1[tt], bias); else S4[tt] = taps_rot.tile(b0[tt], b1[tt], bias);
+                });
+                static_for<0, TG>([&](auto tc) {
+                    constexpr int tt = decltype(tc)::value;
+                    const int t = wv * TPW + g0 + tt;
+                    const int e[4] = { (int)c01[tt].x >> 16, (int)(int16_t)c01[tt].y, (int)c01[tt].y >> 16, (int)(int16_t)c2[tt] };
+                    int y[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        // acc = S +- (e << 11);  y = (acc << SHL) >> 11 with the 32-bit wrap of the reference's accumulator
+                        const int acc = __mul24(e[i], (i & 1) ? m_odd : m_even) + S4[tt][i];
+                        y[i] = (int)((uint32_t)acc << SHL) >> (HB_SHIFT - 1);
+                    }
+                    const int blk = 8 * t + bn;
+                    if constexpr (s < L) {
+                        if constexpr (NEXT16) {
+#pragma unroll
+                            for (int i = 0; i < 4; i++) ovf_or |= (uint32_t)y[i] + 0x8000u;
+                            const int p = HIST / 2 + 4 * blk + g4;
+                            nI[comp * arr2 + p] = pack_iq(y[1], y[3]) ^ HBM_BIAS2;               // odd arm of the next stage
+                            nI[(2 + comp) * arr2 + p] = pack_iq(y[0], y[2]);                     // even arm
+                        } else {
+                            int* d = reinterpret_cast<int*>(nI);                                 // stage 4: int32 arms oI, oQ, eI, eQ
+                            const int p = HIST + 8 * blk + 2 * g4;
+                            d[comp * arr2 + p] = y[1]; d[comp * arr2 + p + 1] = y[3];
+                            d[(2 + comp) * arr2 + p] = y[0]; d[(2 + comp) * arr2 + p + 1] = y[2];
+                        }
+                    } else {
+                        // last stage: the partner lane (n ^ 8, same row of 16) holds the other component of the same four outputs;
+                        // the I lane stores outputs 0, 1 and the Q lane outputs 2, 3 after one DPP exchange (row_ror:8)
+                        const uint32_t p01 = pack_iq(y[0] >> post, y[1] >> post), p23 = pack_iq(y[2] >> post, y[3] >> post);
+                        const uint32_t keep = comp ? p23 : p01, snd = comp ? p01 : p23;
+                        const uint32_t rcv = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd, 0x128, 0xf, 0xf, true);
+                        const uint32_t rep = comp ? rcv : keep, imp = comp ? keep : rcv;
+                        if (live) {
+                            const long base = sub * NOUT + 16 * blk + 4 * g4 + 2 * comp;
+                            if (base < n_out)     out[base]     = __builtin_amdgcn_perm(imp, rep, 0x05040100u);
+                            if (base + 1 < n_out) out[base + 1] = __builtin_amdgcn_perm(imp, rep, 0x07060302u);
+                        }
+                    }
+                });
+                });
+            } else if constexpr (s <= 3) {
                 constexpr int R = 16 >> s;                     // 8, 4, 2
                 int yI[R], yQ[R];
                 stage_pk16<64, MODE, (s == 1 ? PRE : 0), R>(iI, iQ, jI, jQ, lane, yI, yQ, MODE == MODE_CEN ? ctab_cen : ctab_rot);

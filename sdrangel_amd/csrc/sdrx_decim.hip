@@ -123,7 +123,8 @@ __global__ void decim_serial_kernel(const SerialJob jb)
 typedef void (*chain_fn)(const DecimJobs, int, int, int);
 typedef void (*fast_fn)(const DecimJobs, int, int, int);
 
-struct ChainEntry { chain_fn fn; fast_fn fast; const char* name; const char* fast_name; int lds; int fast_lds; fast_fn fast4; const char* fast4_name; int fast4_lds; };
+struct ChainEntry { chain_fn fn; fast_fn fast; const char* name; const char* fast_name; int lds; int fast_lds; fast_fn fast4; const char* fast4_name; int fast4_lds;
+                    fast_fn fast_mx; fast_fn fast4_mx; };      // the FAST kernels with stages 1-3 on the matrix cores (the default engine)
 
 template<int L, int FC, int PRE, bool U8> static ChainEntry entry()
 {
@@ -131,9 +132,10 @@ template<int L, int FC, int PRE, bool U8> static ChainEntry entry()
     snprintf(name, sizeof name, "decim_chain_kernel<%d,%d,%d,%d>", L, FC, PRE, (int)U8);
     snprintf(fname, sizeof fname, "decim_fast_kernel<%d,%d,%d,%d,1>", L, FC, PRE, (int)U8);
     snprintf(f4name, sizeof f4name, "decim_fast_kernel<%d,%d,%d,%d,4>", L, FC, PRE, (int)U8);
-    return ChainEntry{ &decim_chain_kernel<L, FC, PRE, U8>, &decim_fast_kernel<L, FC, PRE, U8, 1>, name, fname,
+    return ChainEntry{ &decim_chain_kernel<L, FC, PRE, U8>, &decim_fast_kernel<L, FC, PRE, U8, 1, false>, name, fname,
                        dc_lds_dwords(L) * 4, df_lds_dwords(L) * 4,
-                       &decim_fast_kernel<L, FC, PRE, U8, 4>, f4name, df_lds_dwords(L, 4 * DF_SUB) * 4 };
+                       &decim_fast_kernel<L, FC, PRE, U8, 4, false>, f4name, df_lds_dwords(L, 4 * DF_SUB) * 4,
+                       &decim_fast_kernel<L, FC, PRE, U8, 1, true>, &decim_fast_kernel<L, FC, PRE, U8, 4, true> };
 }
 
 // decimation_shifts<16,InputBits> (decimators.h:25-185)
@@ -196,7 +198,8 @@ struct sdrx_decim {
     bool rings_live = false;
     long since_load = 0;
     int path = 0;                 // 0 auto (FAST + flagged EXACT), 1 exact only, 2 fast only (debug: no fallback)
-    ChainEntry k{ nullptr, nullptr, "", "", 0, 0, nullptr, "", 0 };
+    ChainEntry k{ nullptr, nullptr, "", "", 0, 0, nullptr, "", 0, nullptr, nullptr };
+    bool mfma = true;             // half-band engine of the FAST kernel: matrix cores unless SDRX_DECIM_ENGINE=valu (read at create)
     char last_name[96] = "";
     int last_grid = 0, last_block = 0, last_lds = 0;
     EventTimer timer;
@@ -397,9 +400,10 @@ static int launch_batch(sdrx_decim* const* hs, int n, const void* const* d_iq_in
             if (spw > max_sub) spw = max_sub;
         }
         const long segs = (max_sub + spw - 1) / spw;
-        hipLaunchKernelGGL(nw == 1 ? h->k.fast : h->k.fast4, dim3((unsigned)segs, (unsigned)n), dim3(64 * nw), 0, h->stream, jobs, (int)spw, h->post, h->in_shift);
+        hipLaunchKernelGGL(h->mfma ? (nw == 1 ? h->k.fast_mx : h->k.fast4_mx) : (nw == 1 ? h->k.fast : h->k.fast4),
+                           dim3((unsigned)segs, (unsigned)n), dim3(64 * nw), 0, h->stream, jobs, (int)spw, h->post, h->in_shift);
         SDRX_HIP(hipGetLastError());
-        snprintf(h->last_name, sizeof h->last_name, "%s", nw == 1 ? h->k.fast_name : h->k.fast4_name);
+        snprintf(h->last_name, sizeof h->last_name, "%s%s", nw == 1 ? h->k.fast_name : h->k.fast4_name, h->mfma ? "+mfma" : "");
         h->last_grid = (int)(segs * n); h->last_block = 64 * nw; h->last_lds = nw == 1 ? h->k.fast_lds : h->k.fast4_lds;
     }
     if (h->path != 2) {
@@ -609,6 +613,7 @@ static int create_common(sdrx_decim_t** out, int device, int log2_decim, int fcp
     h->group = group_int16(log2_decim, fcpos);
     h->cus = device_cu_count(device);
     { const char* pe = getenv("SDRX_DECIM_PATH"); h->path = !pe ? 0 : !strcmp(pe, "exact") ? 1 : !strcmp(pe, "fast") ? 2 : 0; }
+    { const char* pe = getenv("SDRX_DECIM_ENGINE"); h->mfma = !(pe && !strcmp(pe, "valu")); }
     if (log2_decim > 0 && !pick(log2_decim, fcpos, h->pre, u8, &h->k)) {
         delete h; set_error("sdrx_decim_create: no kernel for this configuration"); return SDRX_EINVAL;
     }
