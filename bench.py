@@ -114,7 +114,12 @@ def cpu_decim(log2: int, sample_cplx: int, reps: int, n_thr: int, seed: int = 12
     L, kind, so = _ref_lib()
     if L is not None:
         mk = lambda: L.ref_decim_new(12)
-        run = lambda h, buf, out: L.ref_decim_process(h, log2, 2, buf.ctypes.data, buf.size, out.ctypes.data)
+        if hasattr(L, "ref_decim_run"):
+            # the call as sdrangelbench times it: the output vector is allocated once and the result stays in it
+            L.ref_decim_run.restype = C.c_int; L.ref_decim_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int32]
+            run = lambda h, buf, out: L.ref_decim_run(h, log2, 2, buf.ctypes.data, buf.size)
+        else:
+            run = lambda h, buf, out: L.ref_decim_process(h, log2, 2, buf.ctypes.data, buf.size, out.ctypes.data)
     else:
         P = _port_lib()
         mk = lambda: P.sdro_decim_new(log2, 2, 12)

@@ -30,6 +30,7 @@ namespace {
 struct DecimBase {
     virtual ~DecimBase() {}
     virtual void run(int log2, int fcpos, SampleVector::iterator* it, const qint16* buf, qint32 len) = 0;
+    SampleVector keep;            // ref_decim_run: the output vector of the bench loop, allocated once (sdrbench/mainbench.cpp:83-104)
 };
 
 // fcpos: 0 = infradyne (_inf), 1 = supradyne (_sup), 2 = centre (_cen) -- same coding as the
@@ -115,6 +116,17 @@ int ref_decim_process(void* h, int log2, int fcpos, const int16_t* buf, int32_t 
     int n = (int)(it - v.begin());
     for (int i = 0; i < n; i++) { out[2*i] = v[i].real(); out[2*i+1] = v[i].imag(); }
     return n;
+}
+
+// The call as sdrangelbench times it (sdrbench/mainbench.cpp:83-104): the output SampleVector lives across calls and the
+// result stays in it -- no allocation and no copy-out inside the timed loop.  Returns the number of outputs.
+int ref_decim_run(void* h, int log2, int fcpos, const int16_t* buf, int32_t len)
+{
+    DecimBase* d = static_cast<DecimBase*>(h);
+    if ((int)d->keep.size() < len / 2 + 8) d->keep.resize((size_t)(len / 2 + 8));
+    SampleVector::iterator it = d->keep.begin();
+    d->run(log2, fcpos, &it, buf, len);
+    return (int)(it - d->keep.begin());
 }
 
 // modes[i]: 0 = centre, 1 = lower half, 2 = upper half (DownChannelizer::FilterStage::Mode order,

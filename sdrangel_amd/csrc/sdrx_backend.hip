@@ -278,7 +278,7 @@ int sdrx_backend_create(sdrx_backend_t** out, int device, int32_t n_ch, const sd
         s.half = flen / 2;
         for (int i = 0; i < 2; i++) {
             BE_TRY(hipMalloc(reinterpret_cast<void**>(&h.hist[i]), BE_HIST * 4));
-            BE_TRY(hipMemset(h.hist[i], 0, BE_HIST * 4));
+            BE_TRY(hipMemsetAsync(h.hist[i], 0, BE_HIST * 4, b->stream));   // on the handle's own (non-blocking) stream: ordered before its kernels
         }
     }
     // schedule columns: channels sorted by tap table, so that a FIR tile of 16 columns normally sees one design

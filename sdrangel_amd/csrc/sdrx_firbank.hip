@@ -138,7 +138,7 @@ int sdrx_firbank_create(sdrx_firbank_t** out, int device, int32_t n_ch, const sd
         b->taps_all.insert(b->taps_all.end(), t.begin(), t.end());
         for (int q = 0; q < 2; q++) {
             FB_TRY(hipMalloc(reinterpret_cast<void**>(&b->hist[q][(size_t)c]), (size_t)N * 4));
-            FB_TRY(hipMemset(b->hist[q][(size_t)c], 0, (size_t)N * 4));
+            FB_TRY(hipMemsetAsync(b->hist[q][(size_t)c], 0, (size_t)N * 4, b->stream));   // the handle's own stream orders it before the kernels
         }
     }
     FB_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_taps), b->taps_all.size() * 4));

@@ -17,7 +17,8 @@ def lib(fast: bool = False):
         _sig(L)
         return L
     if _lib is None:
-        _lib = C.CDLL(os.path.join(ROOT, "oracle", "libsdro.so"))
+        # SDRO_LIB: another build of the same restatement (tests/test_sanitizers.py points it at the ASan/UBSan build)
+        _lib = C.CDLL(os.environ.get("SDRO_LIB") or os.path.join(ROOT, "oracle", "libsdro.so"))
         _sig(_lib)
     return _lib
 
