@@ -229,7 +229,7 @@ __host__ __device__ constexpr int df_lds_dwords(int L, int S = DF_SUB) { return 
 // cores (hb_mfma.hpp: v_mfma_i32_16x16x64_i8, exact int32 sums) instead of v_dot2c; same LDS layout, same overflow guard,
 // same int32 tail stages.  The odd arms those stages read carry 0x0080 XORed into every int16 (the primitive's byte bias).
 template<int L, int FC, int PRE, bool U8, int NW, bool MX>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MX && NW == 1 ? 3 : 1)))
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MX ? 3 : 1)))
 void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
 {
     typedef typename Quad<U8>::T QT;
@@ -291,145 +291,207 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
     uint32_t ovf_or = 0;                                       // OR of (y + 0x8000) over every int16-stored output so far
     __syncthreads();
 
-    for (long sub = first - WARM; sub < last; ++sub) {
-        {
-            uint32_t* oI = lds + df_off(1, S), *oQ = oI + df_arr(1, S), *eI = oQ + df_arr(1, S), *eQ = eI + df_arr(1, S);
+    // raw sub-chunk (already in registers) -> the four packed arms of stage 1
+    auto split_in = [&]() {
+        uint32_t* oI = lds + df_off(1, S), *oQ = oI + df_arr(1, S), *eI = oQ + df_arr(1, S), *eQ = eI + df_arr(1, S);
 #pragma unroll
-            for (int j = 0; j < LPT; j++) {
-                const int q = HIST / 2 + j * NT + lane;
-                Quad<U8>::split(pre[j], in_shift, eI[q], eQ[q], oI[q], oQ[q]);
-                if constexpr (MX) { oI[q] ^= HBM_BIAS2; oQ[q] ^= HBM_BIAS2; }
+        for (int j = 0; j < LPT; j++) {
+            const int q = HIST / 2 + j * NT + lane;
+            uint32_t a, b, c, d;
+            Quad<U8>::split(pre[j], in_shift, a, b, c, d);
+            eI[q] = a; eQ[q] = b;
+            if constexpr (MX) { oI[q] = c ^ HBM_BIAS2; oQ[q] = d ^ HBM_BIAS2; } else { oI[q] = c; oQ[q] = d; }
+        }
+    };
+    // stage s over sub-chunk `sub` (arrays of stage s -> arrays of stage s + 1, or the output when s == L and `live`)
+    auto do_stage = [&](auto sc, const long sub, const bool live) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int MODE = dc_mode(L, FC, s);
+        constexpr int NOUT = S >> s;
+        const uint32_t* iI = lds + df_off(s, S), *iQ = iI + df_arr(s, S), *jI = iQ + df_arr(s, S), *jQ = jI + df_arr(s, S);   // oI,oQ,eI,eQ
+        uint32_t* nI = lds + df_off(s + 1, S);                // next stage: oI, oQ, eI, eQ
+        if constexpr (MX && s <= 3) {
+            // ---- the stage on the matrix cores.  A tile = 8 blocks of 16 consecutive outputs of I (columns 0..7) and of Q
+            // (columns 8..15); lane (n, g) ends up with outputs 4g .. 4g+3 of block 8 t + (n & 7) of component n >> 3.
+            constexpr int SHL = (s == 1 ? PRE : 0);
+            constexpr int TPW = 8 >> s;                                // tiles per wave and sub-chunk: 4, 2, 1
+            constexpr int arr = df_arr(s, S), arr2 = df_arr(s + 1, S);
+            constexpr bool NEXT16 = s < L && s + 1 <= 3;              // the outputs are re-read as packed int16 (by an MFMA stage)
+            const int ec = MODE == MODE_CEN ? comp : 1 - comp;         // inf/sup: the centre tap comes from the other component
+            // sign of the centre tap for even / odd outputs: inf: k even -> (+im, -re), k odd -> (-im, +re); sup: negated
+            const int m_even = MODE == MODE_CEN ? 2048 : ((comp == 0) == (MODE == MODE_INF) ? 2048 : -2048);
+            const int m_odd = MODE == MODE_CEN ? 2048 : -m_even;
+            const uint32_t* ob = iI + comp * arr + 8 * bn + 4 * g4;    // window entry 0 of block bn: int16 index 16 blk
+            const uint32_t* eb = jI + ec * arr + 8 * bn + 2 * g4 + 8;  // centre taps e[k - 15]: int16 entries 16 blk + 4 g + 17 + i
+            constexpr int BIASV = MODE == MODE_CEN ? HbMfmaTaps<64, false>::BIAS : HbMfmaTaps<64, true>::BIAS;
+            const v4i bias = { BIASV, BIASV, BIASV, BIASV };
+            // every load of the stage's tiles first, then the MFMAs, then the epilogues: the stores of one tile must not sit
+            // between the loads of the next (same LDS array as far as the compiler can tell)
+            // (two tiles at a time: four in flight cost 160 VGPRs and a wave per SIMD)
+            constexpr int TG = TPW < 2 ? TPW : 2;
+            static_for<0, TPW / TG>([&](auto gc) {
+            constexpr int g0 = decltype(gc)::value * TG;
+            v4i b0[TG], b1[TG], S4[TG]; uint2 c01[TG]; uint32_t c2[TG];
+            static_for<0, TG>([&](auto tc) {
+                constexpr int tt = decltype(tc)::value;
+                const int t = wv * TPW + g0 + tt;
+                b0[tt] = *reinterpret_cast<const v4i*>(__builtin_assume_aligned(ob + 64 * t, 16));
+                b1[tt] = *reinterpret_cast<const v4i*>(__builtin_assume_aligned(ob + 64 * t + 16, 16));
+                c01[tt] = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(eb + 64 * t, 8));
+                c2[tt] = eb[64 * t + 2];
+            });
+            static_for<0, TG>([&](auto tc) {
+                constexpr int tt = decltype(tc)::value;
+                if constexpr (MODE == MODE_CEN) S4[tt] = taps_cen.tile(b0[tt], b1[tt], bias); else S4[tt] = taps_rot.tile(b0[tt], b1[tt], bias);
+            });
+            static_for<0, TG>([&](auto tc) {
+                constexpr int tt = decltype(tc)::value;
+                const int t = wv * TPW + g0 + tt;
+                const int e[4] = { (int)c01[tt].x >> 16, (int)(int16_t)c01[tt].y, (int)c01[tt].y >> 16, (int)(int16_t)c2[tt] };
+                int y[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    // acc = S +- (e << 11);  y = (acc << SHL) >> 11 with the 32-bit wrap of the reference's accumulator
+                    const int acc = __mul24(e[i], (i & 1) ? m_odd : m_even) + S4[tt][i];
+                    y[i] = (int)((uint32_t)acc << SHL) >> (HB_SHIFT - 1);
+                }
+                const int blk = 8 * t + bn;
+                if constexpr (s < L) {
+                    if constexpr (NEXT16) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) ovf_or |= (uint32_t)y[i] + 0x8000u;
+                        const int p = HIST / 2 + 4 * blk + g4;
+                        nI[comp * arr2 + p] = pack_iq(y[1], y[3]) ^ HBM_BIAS2;               // odd arm of the next stage
+                        nI[(2 + comp) * arr2 + p] = pack_iq(y[0], y[2]);                     // even arm
+                    } else {
+                        int* d = reinterpret_cast<int*>(nI);                                 // stage 4: int32 arms oI, oQ, eI, eQ
+                        const int p = HIST + 8 * blk + 2 * g4;
+                        d[comp * arr2 + p] = y[1]; d[comp * arr2 + p + 1] = y[3];
+                        d[(2 + comp) * arr2 + p] = y[0]; d[(2 + comp) * arr2 + p + 1] = y[2];
+                    }
+                } else {
+                    // last stage: the partner lane (n ^ 8, same row of 16) holds the other component of the same four outputs;
+                    // the I lane stores outputs 0, 1 and the Q lane outputs 2, 3 after one DPP exchange (row_ror:8)
+                    const uint32_t p01 = pack_iq(y[0] >> post, y[1] >> post), p23 = pack_iq(y[2] >> post, y[3] >> post);
+                    const uint32_t keep = comp ? p23 : p01, snd = comp ? p01 : p23;
+                    const uint32_t rcv = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd, 0x128, 0xf, 0xf, true);
+                    const uint32_t rep = comp ? rcv : keep, imp = comp ? keep : rcv;
+                    if (live) {
+                        const long base = sub * NOUT + 16 * blk + 4 * g4 + 2 * comp;
+                        if (base < n_out)     out[base]     = __builtin_amdgcn_perm(imp, rep, 0x05040100u);
+                        if (base + 1 < n_out) out[base + 1] = __builtin_amdgcn_perm(imp, rep, 0x07060302u);
+                    }
+                }
+            });
+            });
+        } else if constexpr (s <= 3) {
+            constexpr int R = 16 >> s;                     // 8, 4, 2
+            int yI[R], yQ[R];
+            stage_pk16<64, MODE, (s == 1 ? PRE : 0), R>(iI, iQ, jI, jQ, lane, yI, yQ, MODE == MODE_CEN ? ctab_cen : ctab_rot);
+            if constexpr (s < L) {
+                if constexpr (s + 1 <= 3) {
+                    // these outputs are re-read as int16: y fits iff (y + 0x8000) has no bit above 15.  add + or
+                    // are full-rate VALU ops on gfx950, v_max/v_min are half rate (profiles/r01_valu_issue_rates.txt)
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+                        ovf_or |= ((uint32_t)yI[r] + 0x8000u) | ((uint32_t)yQ[r] + 0x8000u);
+                    put_pk16<R>(nI, nI + df_arr(s + 1, S), nI + 2 * df_arr(s + 1, S), nI + 3 * df_arr(s + 1, S), lane, yI, yQ);
+                } else {
+                    int* d = reinterpret_cast<int*>(nI);
+                    put_i32<R>(d, d + df_arr(s + 1, S), d + 2 * df_arr(s + 1, S), d + 3 * df_arr(s + 1, S), lane, yI, yQ);
+                }
+            } else if (live) {
+                const long base = sub * NOUT + (long)R * lane;
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                    if (base + r < n_out) out[base + r] = pack_iq(yI[r] >> post, yQ[r] >> post);
+            }
+        } else {
+            constexpr int SPLIT = s == 4 ? 1 : s == 5 ? 2 : 4;
+            int y[2], p, comp;
+            stage_i32_split<MODE, SPLIT, true>(reinterpret_cast<const int*>(iI), reinterpret_cast<const int*>(iQ),
+                                               reinterpret_cast<const int*>(jI), reinterpret_cast<const int*>(jQ),
+                                               lane, y, p, comp);
+            if constexpr (s < L) {
+                int* d = reinterpret_cast<int*>(nI);       // oI, oQ, eI, eQ of the next stage
+                int* od = d + (comp ? df_arr(s + 1, S) : 0);
+                int* ed = d + (comp ? 3 * df_arr(s + 1, S) : 2 * df_arr(s + 1, S));
+                ed[HIST + p] = y[0]; od[HIST + p] = y[1];
+            } else {
+                // partner component sits SPLIT lanes up; lanes with comp == 0 and slice 0 store
+                // lane + SPLIT: quad_perm [1,2,3,3] / [2,3,3,3] inside a quad, row_shl:4 across quads (only lanes whose partner exists store)
+                constexpr int DN = SPLIT == 1 ? 0xF9 : SPLIT == 2 ? 0xFE : 0x104;
+                const int q0 = __builtin_amdgcn_mov_dpp(y[0], DN, 0xf, 0xf, true), q1 = __builtin_amdgcn_mov_dpp(y[1], DN, 0xf, 0xf, true);
+                if (live && comp == 0 && (lane % SPLIT) == 0) {
+                    const long base = sub * NOUT + 2 * p;
+                    if (base < n_out)     out[base]     = pack_iq(y[0] >> post, q0 >> post);
+                    if (base + 1 < n_out) out[base + 1] = pack_iq(y[1] >> post, q1 >> post);
+                }
             }
         }
+    };
+
+    if constexpr (MX && NW == 1) {
+        // ---- SKEWED pipeline (single-wave workgroups, matrix-core engine): in iteration `it` stage s works on sub-chunk it - (s - 1),
+        // highest stage first.  A stage reads only what the PREVIOUS iteration wrote, so nothing inside an iteration waits for
+        // anything else inside it: no fence between the stages (one per iteration), the LDS reads of a stage overlap the MFMAs and
+        // the epilogue of the one before.  L - 1 extra iterations drain the pipe.  Carry: the tails of all arrays are read at the
+        // top of the iteration (nothing has been overwritten yet); an array's head is rewritten right after its consumer stage has
+        // read it -- stage 1's array before the next raw sub-chunk is split into it.
+        const auto cbar = [] { asm volatile("" ::: "memory"); };            // compiler-only: LDS operations of one wave execute in order
+        for (long it = first - WARM; it < last + (L - 1); ++it) {
+            uint32_t keep[L][2];
+            static_for<1, L + 1>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                constexpr int HD = df_in16(s) ? HIST / 2 : HIST;
+                constexpr int ND = df_in16(s) ? (S >> (s + 1)) : (S >> s);
+                constexpr int PER = 4 * HD / NT;
+                const uint32_t* a = lds + df_off(s, S);
+#pragma unroll
+                for (int q = 0; q < PER; q++) { const int i = q * NT + lane; keep[s - 1][q] = a[(i / HD) * df_arr(s, S) + ND + (i % HD)]; }
+            });
+            cbar();
+            auto put_head = [&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                constexpr int HD = df_in16(s) ? HIST / 2 : HIST;
+                constexpr int PER = 4 * HD / NT;
+                uint32_t* a = lds + df_off(s, S);
+#pragma unroll
+                for (int q = 0; q < PER; q++) { const int i = q * NT + lane; a[(i / HD) * df_arr(s, S) + (i % HD)] = keep[s - 1][q]; }
+            };
+            put_head(std::integral_constant<int, 1>{});                         // stage 1 read this array in the previous iteration
+            cbar();
+            if (it < last) {
+                split_in();
+                if (it + 1 < last) fetch(it + 1);
+            }
+            cbar();
+            static_for<0, L>([&](auto ic) {
+                constexpr int s = L - decltype(ic)::value;
+                const long sub = it - (s - 1);
+                if (sub >= first - WARM && sub < last) do_stage(std::integral_constant<int, s>{}, sub, sub >= first);
+                cbar();
+                if constexpr (s >= 2) put_head(std::integral_constant<int, s>{});
+                cbar();
+            });
+            if constexpr (L >= 2) { if (!bad && __any((ovf_or >> 16) != 0)) bad = true; }
+            const long subL = it - (L - 1);
+            // conservative: `bad` may already hold an overflow of a LATER sub-chunk (stage 1 is L - 1 sub-chunks ahead)
+            if (subL >= first && subL < last && lane == 0 && ((subL + 1) % (DF_CHUNK / S) == 0 || subL + 1 == last))
+                ovf_flags[subL / (DF_CHUNK / S)] = bad ? 1u : 0u;
+            __syncthreads();                                                    // single wave: a fence, no s_barrier
+        }
+        return;
+    }
+
+    for (long sub = first - WARM; sub < last; ++sub) {
+        split_in();
         if (sub + 1 < last) fetch(sub + 1);
         __syncthreads();                                       // single-wave workgroup: a fence, no s_barrier
 
         const bool live = sub >= first;
         static_for<1, L + 1>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            constexpr int MODE = dc_mode(L, FC, s);
-            constexpr int NOUT = S >> s;
-            const uint32_t* iI = lds + df_off(s, S), *iQ = iI + df_arr(s, S), *jI = iQ + df_arr(s, S), *jQ = jI + df_arr(s, S);   // oI,oQ,eI,eQ
-            uint32_t* nI = lds + df_off(s + 1, S);                // next stage: oI, oQ, eI, eQ
-            if constexpr (MX && s <= 3) {
-                // ---- the stage on the matrix cores.  A tile = 8 blocks of 16 consecutive outputs of I (columns 0..7) and of Q
-                // (columns 8..15); lane (n, g) ends up with outputs 4g .. 4g+3 of block 8 t + (n & 7) of component n >> 3.
-                constexpr int SHL = (s == 1 ? PRE : 0);
-                constexpr int TPW = 8 >> s;                                // tiles per wave and sub-chunk: 4, 2, 1
-                constexpr int arr = df_arr(s, S), arr2 = df_arr(s + 1, S);
-                constexpr bool NEXT16 = s < L && s + 1 <= 3;              // the outputs are re-read as packed int16 (by an MFMA stage)
-                const int ec = MODE == MODE_CEN ? comp : 1 - comp;         // inf/sup: the centre tap comes from the other component
-                // sign of the centre tap for even / odd outputs: inf: k even -> (+im, -re), k odd -> (-im, +re); sup: negated
-                const int m_even = MODE == MODE_CEN ? 2048 : ((comp == 0) == (MODE == MODE_INF) ? 2048 : -2048);
-                const int m_odd = MODE == MODE_CEN ? 2048 : -m_even;
-                const uint32_t* ob = iI + comp * arr + 8 * bn + 4 * g4;    // window entry 0 of block bn: int16 index 16 blk
-                const uint32_t* eb = jI + ec * arr + 8 * bn + 2 * g4 + 8;  // centre taps e[k - 15]: int16 entries 16 blk + 4 g + 17 + i
-                constexpr int BIASV = MODE == MODE_CEN ? HbMfmaTaps<64, false>::BIAS : HbMfmaTaps<64, true>::BIAS;
-                const v4i bias = { BIASV, BIASV, BIASV, BIASV };
-                // every load of the stage's tiles first, then the MFMAs, then the epilogues: the stores of one tile must not sit
-                // between the loads of the next (same LDS array as far as the compiler can tell)
-                // (two tiles at a time: four in flight cost 160 VGPRs and a wave per SIMD)
-                constexpr int TG = TPW < 2 ? TPW : 2;
-                static_for<0, TPW / TG>([&](auto gc) {
-                constexpr int g0 = decltype(gc)::value * TG;
-                v4i b0[TG], b1[TG], S4[TG]; uint2 c01[TG]; uint32_t c2[TG];
-                static_for<0, TG>([&](auto tc) {
-                    constexpr int tt = decltype(tc)::value;
-                    const int t = wv * TPW + g0 + tt;
-                    b0[tt] = *reinterpret_cast<const v4i*>(__builtin_assume_aligned(ob + 64 * t, 16));
-                    b1[tt] = *reinterpret_cast<const v4i*>(__builtin_assume_aligned(ob + 64 * t + 16, 16));
-                    c01[tt] = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(eb + 64 * t, 8));
-                    c2[tt] = eb[64 * t + 2];
-                });
-                static_for<0, TG>([&](auto tc) {
-                    constexpr int tt = decltype(tc)::value;
-                    if constexpr (MODE == MODE_CEN) S4[tt] = taps_cen.tile(b0[tt], b1[tt], bias); else S4[tt] = taps_rot.tile(b0[tt], b1[tt], bias);
-                });
-                static_for<0, TG>([&](auto tc) {
-                    constexpr int tt = decltype(tc)::value;
-                    const int t = wv * TPW + g0 + tt;
-                    const int e[4] = { (int)c01[tt].x >> 16, (int)(int16_t)c01[tt].y, (int)c01[tt].y >> 16, (int)(int16_t)c2[tt] };
-                    int y[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        // acc = S +- (e << 11);  y = (acc << SHL) >> 11 with the 32-bit wrap of the reference's accumulator
-                        const int acc = __mul24(e[i], (i & 1) ? m_odd : m_even) + S4[tt][i];
-                        y[i] = (int)((uint32_t)acc << SHL) >> (HB_SHIFT - 1);
-                    }
-                    const int blk = 8 * t + bn;
-                    if constexpr (s < L) {
-                        if constexpr (NEXT16) {
-#pragma unroll
-                            for (int i = 0; i < 4; i++) ovf_or |= (uint32_t)y[i] + 0x8000u;
-                            const int p = HIST / 2 + 4 * blk + g4;
-                            nI[comp * arr2 + p] = pack_iq(y[1], y[3]) ^ HBM_BIAS2;               // odd arm of the next stage
-                            nI[(2 + comp) * arr2 + p] = pack_iq(y[0], y[2]);                     // even arm
-                        } else {
-                            int* d = reinterpret_cast<int*>(nI);                                 // stage 4: int32 arms oI, oQ, eI, eQ
-                            const int p = HIST + 8 * blk + 2 * g4;
-                            d[comp * arr2 + p] = y[1]; d[comp * arr2 + p + 1] = y[3];
-                            d[(2 + comp) * arr2 + p] = y[0]; d[(2 + comp) * arr2 + p + 1] = y[2];
-                        }
-                    } else {
-                        // last stage: the partner lane (n ^ 8, same row of 16) holds the other component of the same four outputs;
-                        // the I lane stores outputs 0, 1 and the Q lane outputs 2, 3 after one DPP exchange (row_ror:8)
-                        const uint32_t p01 = pack_iq(y[0] >> post, y[1] >> post), p23 = pack_iq(y[2] >> post, y[3] >> post);
-                        const uint32_t keep = comp ? p23 : p01, snd = comp ? p01 : p23;
-                        const uint32_t rcv = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd, 0x128, 0xf, 0xf, true);
-                        const uint32_t rep = comp ? rcv : keep, imp = comp ? keep : rcv;
-                        if (live) {
-                            const long base = sub * NOUT + 16 * blk + 4 * g4 + 2 * comp;
-                            if (base < n_out)     out[base]     = __builtin_amdgcn_perm(imp, rep, 0x05040100u);
-                            if (base + 1 < n_out) out[base + 1] = __builtin_amdgcn_perm(imp, rep, 0x07060302u);
-                        }
-                    }
-                });
-                });
-            } else if constexpr (s <= 3) {
-                constexpr int R = 16 >> s;                     // 8, 4, 2
-                int yI[R], yQ[R];
-                stage_pk16<64, MODE, (s == 1 ? PRE : 0), R>(iI, iQ, jI, jQ, lane, yI, yQ, MODE == MODE_CEN ? ctab_cen : ctab_rot);
-                if constexpr (s < L) {
-                    if constexpr (s + 1 <= 3) {
-                        // these outputs are re-read as int16: y fits iff (y + 0x8000) has no bit above 15.  add + or
-                        // are full-rate VALU ops on gfx950, v_max/v_min are half rate (profiles/r01_valu_issue_rates.txt)
-#pragma unroll
-                        for (int r = 0; r < R; r++)
-                            ovf_or |= ((uint32_t)yI[r] + 0x8000u) | ((uint32_t)yQ[r] + 0x8000u);
-                        put_pk16<R>(nI, nI + df_arr(s + 1, S), nI + 2 * df_arr(s + 1, S), nI + 3 * df_arr(s + 1, S), lane, yI, yQ);
-                    } else {
-                        int* d = reinterpret_cast<int*>(nI);
-                        put_i32<R>(d, d + df_arr(s + 1, S), d + 2 * df_arr(s + 1, S), d + 3 * df_arr(s + 1, S), lane, yI, yQ);
-                    }
-                } else if (live) {
-                    const long base = sub * NOUT + (long)R * lane;
-#pragma unroll
-                    for (int r = 0; r < R; r++)
-                        if (base + r < n_out) out[base + r] = pack_iq(yI[r] >> post, yQ[r] >> post);
-                }
-            } else {
-                constexpr int SPLIT = s == 4 ? 1 : s == 5 ? 2 : 4;
-                int y[2], p, comp;
-                stage_i32_split<MODE, SPLIT, true>(reinterpret_cast<const int*>(iI), reinterpret_cast<const int*>(iQ),
-                                                   reinterpret_cast<const int*>(jI), reinterpret_cast<const int*>(jQ),
-                                                   lane, y, p, comp);
-                if constexpr (s < L) {
-                    int* d = reinterpret_cast<int*>(nI);       // oI, oQ, eI, eQ of the next stage
-                    int* od = d + (comp ? df_arr(s + 1, S) : 0);
-                    int* ed = d + (comp ? 3 * df_arr(s + 1, S) : 2 * df_arr(s + 1, S));
-                    ed[HIST + p] = y[0]; od[HIST + p] = y[1];
-                } else {
-                    // partner component sits SPLIT lanes up; lanes with comp == 0 and slice 0 store
-                    // lane + SPLIT: quad_perm [1,2,3,3] / [2,3,3,3] inside a quad, row_shl:4 across quads (only lanes whose partner exists store)
-                    constexpr int DN = SPLIT == 1 ? 0xF9 : SPLIT == 2 ? 0xFE : 0x104;
-                    const int q0 = __builtin_amdgcn_mov_dpp(y[0], DN, 0xf, 0xf, true), q1 = __builtin_amdgcn_mov_dpp(y[1], DN, 0xf, 0xf, true);
-                    if (live && comp == 0 && (lane % SPLIT) == 0) {
-                        const long base = sub * NOUT + 2 * p;
-                        if (base < n_out)     out[base]     = pack_iq(y[0] >> post, q0 >> post);
-                        if (base + 1 < n_out) out[base + 1] = pack_iq(y[1] >> post, q1 >> post);
-                    }
-                }
-            }
+            do_stage(sc, sub, live);
             __syncthreads();
         });
 

@@ -23,3 +23,30 @@ def _built():
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libsdro.so"])
     yield
+
+
+# The half-band engines: the matrix-core kernels are the default; the dot2 kernels of rounds
+# 1-2 stay as the second gfx950 implementation.  Every GPU test of the integer decimators and of the channelizer bank
+# runs under BOTH (the libraries read the switch when a handle / a bank plan is created).
+_ENGINE_MODULES = {
+    "test_decim_gpu": "SDRX_DECIM_ENGINE", "test_golden_gpu": "SDRX_DECIM_ENGINE", "test_fullsize_gpu": "SDRX_DECIM_ENGINE",
+    "test_decim_switch_gpu": "SDRX_DECIM_ENGINE", "test_random_splits_gpu": "SDRX_DECIM_ENGINE", "test_decim_batch_gpu": "SDRX_DECIM_ENGINE",
+    "test_chan_gpu": "SDRX_CHAN_ENGINE", "test_wide_banks_gpu": "SDRX_CHAN_ENGINE", "test_bank_fuzz_gpu": "SDRX_CHAN_ENGINE",
+}
+
+
+def pytest_generate_tests(metafunc):
+    mod = metafunc.module.__name__.rsplit(".", 1)[-1]
+    if mod in _ENGINE_MODULES and "hb_engine" in metafunc.fixturenames:
+        metafunc.parametrize("hb_engine", ["mfma", "valu"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def hb_engine(request, monkeypatch):
+    mod = request.module.__name__.rsplit(".", 1)[-1]
+    eng = getattr(request, "param", None)
+    if mod in _ENGINE_MODULES and eng is not None:
+        # test_golden_gpu / test_fullsize_gpu hold decimator AND bank cases: both switches follow the parameter
+        monkeypatch.setenv("SDRX_DECIM_ENGINE", eng)
+        monkeypatch.setenv("SDRX_CHAN_ENGINE", eng)
+    yield eng
