@@ -223,7 +223,10 @@ typedef struct sdrx_backend_cfg {
     int32_t filt_mode;       /* 0 none, 1 runFilt, 2 runSSB usb, 3 runSSB lsb, 4 runDSB  (getDC = true),
                               * 5 runAsym usb, 6 runAsym lsb: fftfilt(f2, 2048) + create_asym_filter(fopp = f1, fin = f2) (atvdemod.cpp:262,647) */
     float   f1, f2;          /* modes 1-3: fftfilt(f1, f2, 1024); mode 4: fftfilt(f2, 2048) (DSBFilter, ssbdemod.cpp:92); normalised to the OUTPUT rate */
-    int32_t discri;          /* 0 none, 1 phaseDiscriminatorDelta (NFM), 2 phaseDiscriminator (UDPSrc) */
+    int32_t discri;          /* 0 none, 1 phaseDiscriminatorDelta (NFM; bit-identical to the strict-IEEE reference),
+                              * 2 phaseDiscriminator (UDPSrc): std::arg = atan2f.  The device evaluates a double atan2 rounded once
+                              * to float: <= 3 ulp from glibc's atan2f (2 measured, tests/test_backend_gpu.py), i.e. outside the
+                              * 1 ulp of the other float stages -- parity with a given reference binary depends on that box's libm. */
     float   fm_scaling;      /* setFMScaling */
 } sdrx_backend_cfg;
 int sdrx_backend_create(sdrx_backend_t** out, int device, int32_t n_ch, const sdrx_backend_cfg* cfg);

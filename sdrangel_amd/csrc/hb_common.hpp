@@ -1,6 +1,8 @@
 // Half-band stage device functions shared by the Decimators chain kernel and the
 // DownChannelizer tree kernel.  gfx950 (CDNA4) only: wave64, v_dot2c_i32_i16, v_mad_i32_i24,
-// v_perm_b32, LDS staged sliding windows.  No MFMA (there is no dense contraction here).
+// v_perm_b32, LDS staged sliding windows.  These are the dot2 (vector-ALU) forms of the stage; since round 3 the stages
+// whose input is int16 run by default on the matrix cores instead (hb_mfma.hpp: the odd-arm FIR as a banded-Toeplitz
+// i8 MFMA contraction, bit-exact) and the functions below are the second gfx950 implementation (SDRX_*_ENGINE=valu).
 //
 // Math (reference: IntHalfbandFilterEO::doFIR,
 // sdrbase/dsp/inthalfbandfiltereo.h:832-870).  For a stage of order N (P = N/4 coefficient
