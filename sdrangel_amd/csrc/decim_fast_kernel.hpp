@@ -220,6 +220,14 @@ __host__ __device__ constexpr int df_arr(int s, int S = DF_SUB)
 }
 __host__ __device__ constexpr int df_off(int s, int S = DF_SUB) { int o = 0; for (int u = 1; u < s; u++) o += 4 * df_arr(u, S); return o; }
 __host__ __device__ constexpr int df_lds_dwords(int L, int S = DF_SUB) { return df_off(L + 1, S); }
+// The same layout with the pitch the MATRIX-CORE TAIL wants (MXT: single-wave matrix-core flavour, stages 4..6 as one MFMA tile): the
+// int32 arrays then have an even pitch (their windows are read as aligned 16-byte vectors); the dot2 tail keeps the odd one.
+template<bool MXT> struct DfLay {
+    static __host__ __device__ constexpr int arr(int s, int S = DF_SUB) { return df_in16(s) ? (HIST / 2 + (S >> (s + 1))) : (HIST + (S >> s) + (MXT ? 0 : 1)); }
+    static __host__ __device__ constexpr int off(int s, int S = DF_SUB) { int o = 0; for (int u = 1; u < s; u++) o += 4 * arr(u, S); return o; }
+    static __host__ __device__ constexpr int total(int L, int S = DF_SUB) { return off(L + 1, S); }
+};
+constexpr uint32_t HBM_BIAS4 = 0x00808080u;       // XORed into every int32 odd-arm entry the matrix-core tail reads (bytes 0..2 as signed)
 
 // NW = waves per workgroup.  NW = 1: the wave-private pipeline described at the top (sub-chunks of 1024 samples, 4 warm-up
 // sub-chunks per segment).  NW = 4: the same lane work on sub-chunks of 4096 samples with a real barrier behind every stage and ONE
@@ -242,20 +250,22 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
     const int n_sub = job.n_units;
     constexpr int S = DF_SUB * NW, NT = 64 * NW, WARM = DF_WARM / NW, LPT = S / 4 / NT;   // 4 uint4 per lane per sub-chunk
     static_assert(NW == 1 || NW == 2 || NW == 4, "warm-up = 4096 samples = a whole number of sub-chunks (2 measured: never the best)");
-    __shared__ __attribute__((aligned(16))) uint32_t lds[df_lds_dwords(L, S)];
+    constexpr bool MXT = MX && NW == 1 && L >= 4;              // stages 4..L as ONE matrix-core tile per iteration (needs the skewed loop)
+    typedef DfLay<MXT> DL;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[DL::total(L, S)];
     const int lane = threadIdx.x;
     const long first = (long)blockIdx.x * spw;
     if (first >= n_sub) return;
     long last = first + spw; if (last > n_sub) last = n_sub;
     const long n_in4 = n_in >> 2, n_out = n_in >> L;
 
-    for (int i = lane; i < df_lds_dwords(L, S); i += NT) lds[i] = 0;
+    for (int i = lane; i < DL::total(L, S); i += NT) lds[i] = 0;
     constexpr int MXS = MX ? (L < 3 ? L : 3) : 0;             // stages 1..MXS run on the matrix cores
     if constexpr (MX) {
         __syncthreads();
         static_for<1, MXS + 1>([&](auto sc) {                  // a zero sample of a biased odd arm is 0x0080
             constexpr int s = decltype(sc)::value;
-            for (int i = lane; i < 2 * df_arr(s, S); i += NT) lds[df_off(s, S) + i] = HBM_BIAS2;
+            for (int i = lane; i < 2 * DL::arr(s, S); i += NT) lds[DL::off(s, S) + i] = HBM_BIAS2;
         });
     }
 
@@ -263,13 +273,56 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
     if constexpr (DF_SGPR_COEF && !MX) { df_coef_fill<64, MODE_CEN>(ctab_cen); df_coef_fill<64, MODE_INF>(ctab_rot); }
     // matrix-core operands: plain taps for centre stages, alternating-sign taps for inf/sup stages (the rotation of the odd arm
     // folded into the taps: exact modulo 2^32).  Only the sets the chain's first three stages use are built.
-    constexpr bool NEED_CEN = MX && (dc_mode(L, FC, 1) == MODE_CEN || (MXS >= 2 && dc_mode(L, FC, 2) == MODE_CEN) || (MXS >= 3 && dc_mode(L, FC, 3) == MODE_CEN));
+    constexpr bool NEED_CEN = MXT || (MX && (dc_mode(L, FC, 1) == MODE_CEN || (MXS >= 2 && dc_mode(L, FC, 2) == MODE_CEN) || (MXS >= 3 && dc_mode(L, FC, 3) == MODE_CEN)));
     constexpr bool NEED_ROT = MX && (dc_mode(L, FC, 1) != MODE_CEN || (MXS >= 2 && dc_mode(L, FC, 2) != MODE_CEN) || (MXS >= 3 && dc_mode(L, FC, 3) != MODE_CEN));
     HbMfmaTaps<64, false> taps_cen; HbMfmaTaps<64, true> taps_rot;
     const int wl = lane & 63, n16 = wl & 15, g4 = wl >> 4, comp = n16 >> 3, bn = n16 & 7;
     const int wv = MX ? __builtin_amdgcn_readfirstlane(lane >> 6) : 0;
     if constexpr (NEED_CEN) taps_cen.init(wl);
     if constexpr (NEED_ROT) taps_rot.init(wl);
+    // ---- matrix-core tail (MXT): stages 4..L of one iteration form ONE pair of tiles.  A tail stage keeps its odd arm as TWO packed
+    // int16 planes -- low halves (biased by 0x8000: u = s + 32768) and high halves of the int32 samples -- so that the int16 primitive
+    // of hb_mfma.hpp and the operands already resident for stages 1..3 serve it: sum h x = 65536 sum h xh + sum h s + 32768 sum h, exact
+    // modulo 2^32 for ANY int32 input like the reference's accumulator (the dot2 tail needs 24-bit differences).  Columns 0..7 = stage 4
+    // (4 blocks x I, Q), 8..11 = stage 5, 12..13 = stage 6; the stages work on different sub-chunks (skewed loop), so they are independent.
+    // The rotation of an inf/sup stage's odd arm is applied by its PRODUCER (int32: -x is exact modulo 2^32): every column uses the plain taps.
+    // Layout of a tail stage (same 4 (32 + n) dwords as four int32 arms): oI.lo oI.hi oQ.lo oQ.hi (16 + n / 2 dwords each) eI eQ (32 + n each).
+    int t_lo = 0, t_pp = 0, t_co = 0, t_no = 0, t_npp = 0, t_ne = 0, t_blk = 0, t_stage = 4;
+    uint32_t t_me = 0, t_mo = 0, t_ng = 0;
+    bool t_act = false, t_next = false;
+    if constexpr (MXT) {
+        __syncthreads();
+        static_for<4, L + 1>([&](auto sc) {                    // zero samples of the biased planes
+            constexpr int s = decltype(sc)::value;
+            constexpr int pp = HIST / 2 + (S >> (s + 1));
+            for (int i = lane; i < 4 * pp; i += NT) lds[DL::off(s, S) + i] = ((i / pp) & 1) ? HBM_BIAS2 : (HBM_BIAS2 | 0x80008000u);
+        });
+        const int col = n16;
+        t_stage = col < 8 ? 4 : col < 12 ? 5 : 6;
+        t_act = t_stage <= L && col < 14;
+        if (!t_act) t_stage = 4;                                // idle columns mirror a valid one (reads only)
+        t_blk = !t_act ? 0 : t_stage == 4 ? (col >> 1) : t_stage == 5 ? ((col - 8) >> 1) : 0;
+        const int tc = col & 1;
+        auto pick = [&](int a4, int a5, int a6) { return t_stage == 4 ? a4 : t_stage == 5 ? a5 : a6; };
+        constexpr int M4 = dc_mode(L, FC, 4), M5 = L >= 5 ? dc_mode(L, FC, 5) : MODE_CEN, M6 = L >= 6 ? dc_mode(L, FC, 6) : MODE_CEN;
+        const int tmode = pick(M4, M5, M6);
+        const int tn = pick(S >> 4, S >> 5, S >> 6), nn = tn >> 1;              // entries per arm and sub-chunk: this stage, the next one
+        const int toff = pick(DL::off(4, S), DL::off(5, S), DL::off(6, S)), noff = pick(DL::off(5, S), DL::off(6, S), DL::off(7, S));
+        t_pp = HIST / 2 + tn / 2; t_npp = HIST / 2 + nn / 2;
+        const int tec = tmode == MODE_CEN ? tc : 1 - tc;        // inf/sup: the centre tap comes from the other component
+        t_lo = toff + 2 * tc * t_pp + 8 * t_blk + 4 * g4;       // window entry 0 of the block = int16 index 16 blk of the low plane
+        t_co = toff + 4 * t_pp + tec * (HIST + tn) + 16 * t_blk + 4 * g4 + 16;   // centre taps e[k - 15]: int32 entries 16 blk + 4 g + 17 + i
+        t_next = t_act && t_stage < L;
+        t_no = noff + 2 * tc * t_npp + HIST / 2 + 4 * t_blk + g4;               // the lane's two odd outputs: one packed dword per plane
+        t_ne = noff + 4 * t_npp + tc * (HIST + nn) + HIST + 8 * t_blk + 2 * g4; // its two even outputs: two int32
+        // centre-tap sign for even / odd outputs (0: +, ~0: -): inf: k even -> (+im, -re), k odd -> (-im, +re); sup: negated
+        const bool neg_even = tmode != MODE_CEN && ((tc == 0) != (tmode == MODE_INF));
+        t_me = tmode == MODE_CEN ? 0u : (neg_even ? ~0u : 0u);
+        t_mo = tmode == MODE_CEN ? 0u : (neg_even ? 0u : ~0u);
+        // the consumer's rotation of the odd arm, applied here: entry index even -> negated
+        const int nmode = pick(M5, M6, MODE_CEN);
+        t_ng = (t_next && nmode != MODE_CEN) ? ~0u : 0u;
+    }
 
     QT pre[LPT];
     // A sub-chunk is either wholly history (sub < 0) or wholly input: the source is chosen with a wave-uniform (scalar)
@@ -293,7 +346,7 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
 
     // raw sub-chunk (already in registers) -> the four packed arms of stage 1
     auto split_in = [&]() {
-        uint32_t* oI = lds + df_off(1, S), *oQ = oI + df_arr(1, S), *eI = oQ + df_arr(1, S), *eQ = eI + df_arr(1, S);
+        uint32_t* oI = lds + DL::off(1, S), *oQ = oI + DL::arr(1, S), *eI = oQ + DL::arr(1, S), *eQ = eI + DL::arr(1, S);
 #pragma unroll
         for (int j = 0; j < LPT; j++) {
             const int q = HIST / 2 + j * NT + lane;
@@ -308,14 +361,14 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
         constexpr int s = decltype(sc)::value;
         constexpr int MODE = dc_mode(L, FC, s);
         constexpr int NOUT = S >> s;
-        const uint32_t* iI = lds + df_off(s, S), *iQ = iI + df_arr(s, S), *jI = iQ + df_arr(s, S), *jQ = jI + df_arr(s, S);   // oI,oQ,eI,eQ
-        uint32_t* nI = lds + df_off(s + 1, S);                // next stage: oI, oQ, eI, eQ
+        const uint32_t* iI = lds + DL::off(s, S), *iQ = iI + DL::arr(s, S), *jI = iQ + DL::arr(s, S), *jQ = jI + DL::arr(s, S);   // oI,oQ,eI,eQ
+        uint32_t* nI = lds + DL::off(s + 1, S);                // next stage: oI, oQ, eI, eQ
         if constexpr (MX && s <= 3) {
             // ---- the stage on the matrix cores.  A tile = 8 blocks of 16 consecutive outputs of I (columns 0..7) and of Q
             // (columns 8..15); lane (n, g) ends up with outputs 4g .. 4g+3 of block 8 t + (n & 7) of component n >> 3.
             constexpr int SHL = (s == 1 ? PRE : 0);
             constexpr int TPW = 8 >> s;                                // tiles per wave and sub-chunk: 4, 2, 1
-            constexpr int arr = df_arr(s, S), arr2 = df_arr(s + 1, S);
+            constexpr int arr = DL::arr(s, S), arr2 = DL::arr(s + 1, S);
             constexpr bool NEXT16 = s < L && s + 1 <= 3;              // the outputs are re-read as packed int16 (by an MFMA stage)
             const int ec = MODE == MODE_CEN ? comp : 1 - comp;         // inf/sup: the centre tap comes from the other component
             // sign of the centre tap for even / odd outputs: inf: k even -> (+im, -re), k odd -> (-im, +re); sup: negated
@@ -364,10 +417,23 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
                         nI[comp * arr2 + p] = pack_iq(y[1], y[3]) ^ HBM_BIAS2;               // odd arm of the next stage
                         nI[(2 + comp) * arr2 + p] = pack_iq(y[0], y[2]);                     // even arm
                     } else {
-                        int* d = reinterpret_cast<int*>(nI);                                 // stage 4: int32 arms oI, oQ, eI, eQ
-                        const int p = HIST + 8 * blk + 2 * g4;
-                        d[comp * arr2 + p] = y[1]; d[comp * arr2 + p + 1] = y[3];
-                        d[(2 + comp) * arr2 + p] = y[0]; d[(2 + comp) * arr2 + p + 1] = y[2];
+                        if constexpr (MXT) {
+                            // matrix-core tail: the odd outputs go to stage 4's two packed planes (low halves biased by 0x8000, both by the
+                            // primitive's 0x0080), stage 4's rotation (if any) applied here: even entry index -> negated; even outputs: int32
+                            constexpr bool ROT4 = dc_mode(L, FC, 4) != MODE_CEN;
+                            constexpr int pp4 = HIST / 2 + (S >> 5), n4 = S >> 4;
+                            const uint32_t y1 = (uint32_t)(ROT4 ? -y[1] : y[1]), y3 = (uint32_t)y[3];
+                            const int q = 2 * comp * pp4 + HIST / 2 + 4 * blk + g4;
+                            nI[q] = __builtin_amdgcn_perm(y3, y1, 0x05040100u) ^ (HBM_BIAS2 | 0x80008000u);
+                            nI[q + pp4] = __builtin_amdgcn_perm(y3, y1, 0x07060302u) ^ HBM_BIAS2;
+                            int* de = reinterpret_cast<int*>(nI) + 4 * pp4 + comp * (HIST + n4) + HIST + 8 * blk + 2 * g4;
+                            de[0] = y[0]; de[1] = y[2];
+                        } else {
+                            int* d = reinterpret_cast<int*>(nI);                             // stage 4: int32 arms oI, oQ, eI, eQ
+                            const int p = HIST + 8 * blk + 2 * g4;
+                            d[comp * arr2 + p] = y[1]; d[comp * arr2 + p + 1] = y[3];
+                            d[(2 + comp) * arr2 + p] = y[0]; d[(2 + comp) * arr2 + p + 1] = y[2];
+                        }
                     }
                 } else {
                     // last stage: the partner lane (n ^ 8, same row of 16) holds the other component of the same four outputs;
@@ -395,10 +461,10 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
 #pragma unroll
                     for (int r = 0; r < R; r++)
                         ovf_or |= ((uint32_t)yI[r] + 0x8000u) | ((uint32_t)yQ[r] + 0x8000u);
-                    put_pk16<R>(nI, nI + df_arr(s + 1, S), nI + 2 * df_arr(s + 1, S), nI + 3 * df_arr(s + 1, S), lane, yI, yQ);
+                    put_pk16<R>(nI, nI + DL::arr(s + 1, S), nI + 2 * DL::arr(s + 1, S), nI + 3 * DL::arr(s + 1, S), lane, yI, yQ);
                 } else {
                     int* d = reinterpret_cast<int*>(nI);
-                    put_i32<R>(d, d + df_arr(s + 1, S), d + 2 * df_arr(s + 1, S), d + 3 * df_arr(s + 1, S), lane, yI, yQ);
+                    put_i32<R>(d, d + DL::arr(s + 1, S), d + 2 * DL::arr(s + 1, S), d + 3 * DL::arr(s + 1, S), lane, yI, yQ);
                 }
             } else if (live) {
                 const long base = sub * NOUT + (long)R * lane;
@@ -414,8 +480,8 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
                                                lane, y, p, comp);
             if constexpr (s < L) {
                 int* d = reinterpret_cast<int*>(nI);       // oI, oQ, eI, eQ of the next stage
-                int* od = d + (comp ? df_arr(s + 1, S) : 0);
-                int* ed = d + (comp ? 3 * df_arr(s + 1, S) : 2 * df_arr(s + 1, S));
+                int* od = d + (comp ? DL::arr(s + 1, S) : 0);
+                int* ed = d + (comp ? 3 * DL::arr(s + 1, S) : 2 * DL::arr(s + 1, S));
                 ed[HIST + p] = y[0]; od[HIST + p] = y[1];
             } else {
                 // partner component sits SPLIT lanes up; lanes with comp == 0 and slice 0 store
@@ -443,31 +509,95 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
             uint32_t keep[L][2];
             static_for<1, L + 1>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
-                constexpr int HD = df_in16(s) ? HIST / 2 : HIST;
-                constexpr int ND = df_in16(s) ? (S >> (s + 1)) : (S >> s);
-                constexpr int PER = 4 * HD / NT;
-                const uint32_t* a = lds + df_off(s, S);
+                const uint32_t* a = lds + DL::off(s, S);
+                if constexpr (MXT && s >= 4) {
+                    // matrix-core tail layout: four packed planes (16 + n / 2 dwords) then two int32 even arms (32 + n)
+                    constexpr int n = S >> s, pp = HIST / 2 + n / 2;
+                    keep[s - 1][0] = a[(lane / 16) * pp + n / 2 + (lane % 16)];
+                    keep[s - 1][1] = a[4 * pp + (lane / 32) * (HIST + n) + n + (lane % 32)];
+                } else {
+                    constexpr int HD = df_in16(s) ? HIST / 2 : HIST;
+                    constexpr int ND = df_in16(s) ? (S >> (s + 1)) : (S >> s);
+                    constexpr int PER = 4 * HD / NT;
 #pragma unroll
-                for (int q = 0; q < PER; q++) { const int i = q * NT + lane; keep[s - 1][q] = a[(i / HD) * df_arr(s, S) + ND + (i % HD)]; }
+                    for (int q = 0; q < PER; q++) { const int i = q * NT + lane; keep[s - 1][q] = a[(i / HD) * DL::arr(s, S) + ND + (i % HD)]; }
+                }
             });
             cbar();
             auto put_head = [&](auto sc) {
                 constexpr int s = decltype(sc)::value;
                 constexpr int HD = df_in16(s) ? HIST / 2 : HIST;
                 constexpr int PER = 4 * HD / NT;
-                uint32_t* a = lds + df_off(s, S);
+                uint32_t* a = lds + DL::off(s, S);
 #pragma unroll
-                for (int q = 0; q < PER; q++) { const int i = q * NT + lane; a[(i / HD) * df_arr(s, S) + (i % HD)] = keep[s - 1][q]; }
+                for (int q = 0; q < PER; q++) { const int i = q * NT + lane; a[(i / HD) * DL::arr(s, S) + (i % HD)] = keep[s - 1][q]; }
             };
             put_head(std::integral_constant<int, 1>{});                         // stage 1 read this array in the previous iteration
             cbar();
             if (it < last) {
                 split_in();
-                if (it + 1 < last) fetch(it + 1);
+                if constexpr (!MXT) { if (it + 1 < last) fetch(it + 1); }
             }
             cbar();
-            static_for<0, L>([&](auto ic) {
-                constexpr int s = L - decltype(ic)::value;
+            if constexpr (MXT) {
+                // ---- stages 4..L: one pair of tiles (low planes, high planes), the int16 primitive with the resident operands
+                const long subS = it - (t_stage - 1);                          // the sub-chunk this lane's stage works on
+                const bool on = t_act && subS >= first - WARM && subS < last;
+                const v4i l0 = *reinterpret_cast<const v4i*>(__builtin_assume_aligned(lds + t_lo, 16));
+                const v4i l1 = *reinterpret_cast<const v4i*>(__builtin_assume_aligned(lds + t_lo + 16, 16));
+                const v4i h0 = *reinterpret_cast<const v4i*>(__builtin_assume_aligned(lds + t_lo + t_pp, 16));
+                const v4i h1 = *reinterpret_cast<const v4i*>(__builtin_assume_aligned(lds + t_lo + t_pp + 16, 16));
+                const v4i cq = *reinterpret_cast<const v4i*>(__builtin_assume_aligned(lds + t_co, 16));
+                const uint32_t c4 = lds[t_co + 4];
+                cbar();
+                // every tail array has been read: its head may move on.  Planes: 4 x 16 dwords, even arms: 2 x 32 dwords per stage.
+                static_for<4, L + 1>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    constexpr int n = S >> s, pp = HIST / 2 + n / 2;
+                    uint32_t* a = lds + DL::off(s, S);
+                    a[(lane / 16) * pp + (lane % 16)] = keep[s - 1][0];
+                    a[4 * pp + (lane / 32) * (HIST + n) + (lane % 32)] = keep[s - 1][1];
+                });
+                cbar();
+                constexpr int BV = HbMfmaTaps<64, false>::BIAS;
+                const v4i biasv = { BV, BV, BV, BV };
+                const v4i SL = taps_cen.tile(l0, l1, biasv), SH = taps_cen.tile(h0, h1, biasv);
+                const uint32_t ce[4] = { (uint32_t)cq[1], (uint32_t)cq[2], (uint32_t)cq[3], c4 };
+                int y[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    // x = 65536 xh + s + 32768:  S = (SH << 16) + SL + 32768 sum h (modulo 2^32)
+                    const uint32_t S4 = ((uint32_t)SH[i] << 16) + (uint32_t)SL[i] + (uint32_t)(32768 * hb_tap_sum<64>());
+                    const uint32_t m = (i & 1) ? t_mo : t_me;                   // acc = S +- (e << 11), 32-bit wrap
+                    const uint32_t acc = S4 + (((ce[i] << (HB_SHIFT - 1)) ^ m) - m);
+                    y[i] = (int)acc >> (HB_SHIFT - 1);
+                }
+                if (on && t_next) {
+                    const uint32_t y1 = ((uint32_t)y[1] ^ t_ng) - t_ng, y3 = (uint32_t)y[3];   // the consumer's rotation: even entry index negated
+                    lds[t_no] = __builtin_amdgcn_perm(y3, y1, 0x05040100u) ^ (HBM_BIAS2 | 0x80008000u);
+                    lds[t_no + t_npp] = __builtin_amdgcn_perm(y3, y1, 0x07060302u) ^ HBM_BIAS2;
+                    int* d = reinterpret_cast<int*>(lds);
+                    *reinterpret_cast<int2*>(d + t_ne) = make_int2(y[0], y[2]);
+                }
+                {
+                    // last stage: the partner lane n ^ 1 holds the other component; the I lane stores outputs 0, 1 and the Q lane 2, 3
+                    const int tc = n16 & 1;
+                    const uint32_t p01 = pack_iq(y[0] >> post, y[1] >> post), p23 = pack_iq(y[2] >> post, y[3] >> post);
+                    const uint32_t keepv = tc ? p23 : p01, snd = tc ? p01 : p23;
+                    const uint32_t rcv = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd, 0xB1, 0xf, 0xf, true);
+                    const uint32_t rep = tc ? rcv : keepv, imp = tc ? keepv : rcv;
+                    if (on && t_stage == L && subS >= first) {
+                        const long base = subS * (S >> L) + 16 * t_blk + 4 * g4 + 2 * tc;
+                        if (base < n_out)     out[base]     = __builtin_amdgcn_perm(imp, rep, 0x05040100u);
+                        if (base + 1 < n_out) out[base + 1] = __builtin_amdgcn_perm(imp, rep, 0x07060302u);
+                    }
+                }
+                cbar();
+                // the prefetch of the next raw sub-chunk goes out HERE: its 16 registers are free while the tile above runs
+                if (it + 1 < last) fetch(it + 1);
+            }
+            static_for<0, (MXT ? 3 : L)>([&](auto ic) {
+                constexpr int s = (MXT ? 3 : L) - decltype(ic)::value;
                 const long sub = it - (s - 1);
                 if (sub >= first - WARM && sub < last) do_stage(std::integral_constant<int, s>{}, sub, sub >= first);
                 cbar();
@@ -513,11 +643,11 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
             constexpr int ND = df_in16(s) ? (S >> (s + 1)) : (S >> s);                // payload dwords per array
             constexpr int TOT = 4 * HD, PER = (TOT + NT - 1) / NT;
             static_assert(TOT % 64 == 0, "four arrays x 16 or 32 history dwords: a whole number of wave-wide accesses");
-            const uint32_t* a = lds + df_off(s, S);
+            const uint32_t* a = lds + DL::off(s, S);
 #pragma unroll
             for (int q = 0; q < PER; q++) {
                 const int i = q * NT + lane;
-                if (NW == 1 || i < TOT) keep[s - 1][q] = a[(i / HD) * df_arr(s, S) + ND + (i % HD)];
+                if (NW == 1 || i < TOT) keep[s - 1][q] = a[(i / HD) * DL::arr(s, S) + ND + (i % HD)];
             }
         });
         __syncthreads();
@@ -525,11 +655,11 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
             constexpr int s = decltype(sc)::value;
             constexpr int HD = df_in16(s) ? HIST / 2 : HIST;
             constexpr int TOT = 4 * HD, PER = (TOT + NT - 1) / NT;
-            uint32_t* a = lds + df_off(s, S);
+            uint32_t* a = lds + DL::off(s, S);
 #pragma unroll
             for (int q = 0; q < PER; q++) {
                 const int i = q * NT + lane;
-                if (NW == 1 || i < TOT) a[(i / HD) * df_arr(s, S) + (i % HD)] = keep[s - 1][q];
+                if (NW == 1 || i < TOT) a[(i / HD) * DL::arr(s, S) + (i % HD)] = keep[s - 1][q];
             }
         });
         __syncthreads();
