@@ -442,8 +442,8 @@ def main():
             bank.feed_dev(x.data_ptr(), B)
             if be is not None:
                 be.feed_bank(bank)               # device-ordered hand-over; the back-end runs on its own stream
-                if not os.environ.get("SDRX_BENCH_CFG4_PIPELINED"):
-                    be.sync()                    # letting the back-end overlap the NEXT step's channelizer measured slower (2.97 vs 2.40 ms/step)
+                if os.environ.get("SDRX_BENCH_CFG4_SERIAL"):
+                    be.sync()                    # default since round 3: the back-end of step k overlaps the channelizer of step k + 1 (6.29 vs 6.54 ms/step)
             for c in range(n_ch):
                 bank.skip(c)
         bps_b, d2_b = bank_figures(bank, n_ch)

@@ -186,6 +186,13 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
 
     uint4 pre[LPT];
     auto fetch = [&](long chunk) {
+        const long c0 = chunk * C;
+        if (c0 >= sp.t_old && c0 + C <= sp.t_new) {               // the whole chunk lies in this feed (wave-uniform): no per-lane tests
+            const uint4* src = reinterpret_cast<const uint4*>(sp.in + (c0 - sp.t_old));
+#pragma unroll
+            for (int j = 0; j < LPT; j++) pre[j] = src[j * NT + tid];
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < LPT; j++) {
             const long p0 = chunk * C + 4 * (j * NT + tid);       // absolute position of the 4 samples
@@ -219,8 +226,10 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
             if (st.rootO_I >= 0) { lds[st.rootO_I + q] = oI ^ root_xm; lds[st.rootO_Q + q] = oQ ^ root_xm; }
             if (st.rootA_I >= 0) {
                 // odd-arm index m even (low half) -> wrap-negated, m odd -> as is
-                lds[st.rootA_I + q] = (((0u - oI) & 0xffffu) | (oI & 0xffff0000u)) ^ root_xm;
-                lds[st.rootA_Q + q] = (((0u - oQ) & 0xffffu) | (oQ & 0xffff0000u)) ^ root_xm;
+                typedef unsigned short us2r __attribute__((ext_vector_type(2)));
+                const us2r sg = { 0xffffu, 1u };                                   // one packed multiply by (-1, +1): the low half wraps
+                lds[st.rootA_I + q] = __builtin_bit_cast(uint32_t, (us2r)(__builtin_bit_cast(us2r, oI) * sg)) ^ root_xm;
+                lds[st.rootA_Q + q] = __builtin_bit_cast(uint32_t, (us2r)(__builtin_bit_cast(us2r, oQ) * sg)) ^ root_xm;
             }
         }
         for (int i = tid; i < st.root_arr_cnt * 16; i += NT) {                 // history in front of the root windows
@@ -331,8 +340,15 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                 auto finish = [&](const JobIn& r, const v4i SI, const v4i SQ, const s8i h, const s8i oa, const s8i ob) {
                     // (S +- (e << 11)) >> 11 == (S >> 11) +- e (|S| < 2^28 for any int16 data), and the int16 store keeps the sum
                     // modulo 2^16: pack the shifted sums and the centre taps first, then add / subtract two outputs per instruction
-                    const uint32_t sI02 = pack_iq(SI[0] >> (HB_SHIFT - 1), SI[2] >> (HB_SHIFT - 1)), sI13 = pack_iq(SI[1] >> (HB_SHIFT - 1), SI[3] >> (HB_SHIFT - 1));
-                    const uint32_t sQ02 = pack_iq(SQ[0] >> (HB_SHIFT - 1), SQ[2] >> (HB_SHIFT - 1)), sQ13 = pack_iq(SQ[1] >> (HB_SHIFT - 1), SQ[3] >> (HB_SHIFT - 1));
+                    // (lo, hi) int16 halves = (a >> 11, b >> 11): the second shift writes its low half straight into the high half of
+                    // the first's result (SDWA, one instruction instead of a shift and a v_perm; a and b are VALU results, no MFMA hazard)
+                    auto shpack = [](int a, int b) {
+                        uint32_t r = (uint32_t)(a >> (HB_SHIFT - 1));
+                        asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(r) : "s"(HB_SHIFT - 1), "v"(b));
+                        return r;
+                    };
+                    const uint32_t sI02 = shpack(SI[0], SI[2]), sI13 = shpack(SI[1], SI[3]);
+                    const uint32_t sQ02 = shpack(SQ[0], SQ[2]), sQ13 = shpack(SQ[1], SQ[3]);
                     // centre taps e0..e3 = int16 entries 1, 2, 3, 4 of the three dwords read: (e0, e2) and (e1, e3)
                     const uint32_t cI02 = __builtin_amdgcn_perm(r.cI01.y, r.cI01.x, 0x07060302u), cI13 = __builtin_amdgcn_perm(r.cI2, r.cI01.y, 0x05040100u);
                     const uint32_t cQ02 = __builtin_amdgcn_perm(r.cQ01.y, r.cQ01.x, 0x07060302u), cQ13 = __builtin_amdgcn_perm(r.cQ2, r.cQ01.y, 0x05040100u);
