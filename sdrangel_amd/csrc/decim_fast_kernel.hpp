@@ -222,8 +222,10 @@ __host__ __device__ constexpr int df_off(int s, int S = DF_SUB) { int o = 0; for
 __host__ __device__ constexpr int df_lds_dwords(int L, int S = DF_SUB) { return df_off(L + 1, S); }
 // The same layout with the pitch the MATRIX-CORE TAIL wants (MXT: single-wave matrix-core flavour, stages 4..6 as one MFMA tile): the
 // int32 arrays then have an even pitch (their windows are read as aligned 16-byte vectors); the dot2 tail keeps the odd one.
-template<bool MXT> struct DfLay {
-    static __host__ __device__ constexpr int arr(int s, int S = DF_SUB) { return df_in16(s) ? (HIST / 2 + (S >> (s + 1))) : (HIST + (S >> s) + (MXT ? 0 : 1)); }
+// PAD (matrix-core engine): the packed arrays of stages 1..3 get 16 more dwords, so that their pitch is 32 mod 64 dwords: a tile reads
+// the I and the Q array in ONE wave instruction (columns alternate I / Q) and 128 bytes between the two keep the ds_read_b128 conflict-free.
+template<bool MXT, bool PAD = false> struct DfLay {
+    static __host__ __device__ constexpr int arr(int s, int S = DF_SUB) { return df_in16(s) ? (HIST / 2 + (S >> (s + 1)) + (PAD ? 16 : 0)) : (HIST + (S >> s) + (MXT ? 0 : 1)); }
     static __host__ __device__ constexpr int off(int s, int S = DF_SUB) { int o = 0; for (int u = 1; u < s; u++) o += 4 * arr(u, S); return o; }
     static __host__ __device__ constexpr int total(int L, int S = DF_SUB) { return off(L + 1, S); }
 };
@@ -251,7 +253,7 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
     constexpr int S = DF_SUB * NW, NT = 64 * NW, WARM = DF_WARM / NW, LPT = S / 4 / NT;   // 4 uint4 per lane per sub-chunk
     static_assert(NW == 1 || NW == 2 || NW == 4, "warm-up = 4096 samples = a whole number of sub-chunks (2 measured: never the best)");
     constexpr bool MXT = MX && NW == 1 && L >= 4;              // stages 4..L as ONE matrix-core tile per iteration (needs the skewed loop)
-    typedef DfLay<MXT> DL;
+    typedef DfLay<MXT, MX> DL;
     __shared__ __attribute__((aligned(16))) uint32_t lds[DL::total(L, S)];
     const int lane = threadIdx.x;
     const long first = (long)blockIdx.x * spw;
@@ -276,7 +278,7 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
     constexpr bool NEED_CEN = MXT || (MX && (dc_mode(L, FC, 1) == MODE_CEN || (MXS >= 2 && dc_mode(L, FC, 2) == MODE_CEN) || (MXS >= 3 && dc_mode(L, FC, 3) == MODE_CEN)));
     constexpr bool NEED_ROT = MX && (dc_mode(L, FC, 1) != MODE_CEN || (MXS >= 2 && dc_mode(L, FC, 2) != MODE_CEN) || (MXS >= 3 && dc_mode(L, FC, 3) != MODE_CEN));
     HbMfmaTaps<64, false> taps_cen; HbMfmaTaps<64, true> taps_rot;
-    const int wl = lane & 63, n16 = wl & 15, g4 = wl >> 4, comp = n16 >> 3, bn = n16 & 7;
+    const int wl = lane & 63, n16 = wl & 15, g4 = wl >> 4, comp = n16 & 1, bn = n16 >> 1;      // tile column n: block n / 2 of component n & 1
     const int wv = MX ? __builtin_amdgcn_readfirstlane(lane >> 6) : 0;
     if constexpr (NEED_CEN) taps_cen.init(wl);
     if constexpr (NEED_ROT) taps_rot.init(wl);
@@ -440,7 +442,7 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
                     // the I lane stores outputs 0, 1 and the Q lane outputs 2, 3 after one DPP exchange (row_ror:8)
                     const uint32_t p01 = pack_iq(y[0] >> post, y[1] >> post), p23 = pack_iq(y[2] >> post, y[3] >> post);
                     const uint32_t keep = comp ? p23 : p01, snd = comp ? p01 : p23;
-                    const uint32_t rcv = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd, 0x128, 0xf, 0xf, true);
+                    const uint32_t rcv = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd, 0xB1, 0xf, 0xf, true);
                     const uint32_t rep = comp ? rcv : keep, imp = comp ? keep : rcv;
                     if (live) {
                         const long base = sub * NOUT + 16 * blk + 4 * g4 + 2 * comp;
