@@ -298,9 +298,9 @@ static int fast_nw(const sdrx_decim* h, long total_in)
 {
     const char* env = getenv("SDRX_DECIM_NW");
     if (env && (atoi(env) == 1 || atoi(env) == 4)) return atoi(env);
-    // matrix-core engine (round 3, gpurun_out/r3b sweep): 4 Mi 168 vs 129 GS/s, 10 M 242 vs 198, 16 Mi 333 vs 310, 32 Mi 439 vs 412,
-    // 64 Mi 489 vs 481, 128 Mi 474 vs 481 -- the four-wave kernel now holds three workgroups per CU (168 VGPRs)
-    if (h->mfma) return total_in <= 96L * 1024 * 1024 ? 4 : 1;
+    // matrix-core engine (round 3 sweep, four-wave vs single-wave; the single-wave flavour has all six stages on the matrix cores):
+    // 4 Mi 170 vs 129 GS/s, 10 M 254 vs 202, 16 Mi 339 vs 323, 32 Mi 448 vs 450, 64 Mi 491 vs 539, 128 Mi 484 vs 525
+    if (h->mfma) return total_in <= 28L * 1024 * 1024 ? 4 : 1;
     return total_in <= 12L * 1024 * 1024 ? 4 : 1;
 }
 
