@@ -376,12 +376,19 @@ static int launch_batch(sdrx_decim* const* hs, int n, const void* const* d_iq_in
             spw = 32; double best = 1e300;
             const char* env = getenv("SDRX_DECIM_SPW");
             if (env && atoi(env) >= 4) spw = (atoi(env) / 4) * 4;
+            else if (h->mfma && tot_sub >= 32 * slots) {
+                // skewed matrix-core kernel: a segment costs spw + 4 warm-up + (L - 1) drain iterations, so long launches want longer
+                // segments (about 4096 of them): 256 Mi samples 0.434 (32) / 0.414 (64) / 0.401 ms (88); 1 Gi 1.42 (64) / 1.38 (128) / 1.41 ms (256)
+                spw = ((tot_sub / 4096 + 3) / 4) * 4;
+                if (spw < 32) spw = 32;
+                if (spw > 128) spw = 128;
+            }
             else if (tot_sub >= 8 * 32 * slots) spw = 64;          // long launches: halve the warm-up share (512 Mi samples: 429 vs 418 GS/s, 1 Gi: 494 vs 471)
             else if (tot_sub < 32 * slots) for (long c = 4; c <= 32; c += 4) {
                 long segs = 0;
                 for (int i = 0; i < n; i++) segs += (jobs.j[i].n_units + c - 1) / c;
                 const long rounds = (segs + slots - 1) / slots;
-                const double cost = (double)(c + DF_WARM) * (double)rounds;
+                const double cost = (double)(c + DF_WARM + (h->mfma ? h->log2 - 1 : 0)) * (double)rounds;
                 if (cost < best - 1e-9) { best = cost; spw = c; }
             }
             if (spw > max_sub) spw = ((max_sub + 3) / 4) * 4;
