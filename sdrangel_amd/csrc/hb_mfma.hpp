@@ -46,33 +46,44 @@ struct HbMfmaTaps {
     static constexpr int T = ORDER / 2;                 // taps of the odd-arm FIR; also the window's lead: entry w = o[16 blk - T + w]
     static constexpr bool P1_STEP2 = (ORDER == 64);     // order 48: the central taps only meet entries 9..31
     static constexpr int BIAS = ALT ? 0 : 128 * hb_tap_sum<ORDER>();   // alternating signs cancel (the taps are symmetric, T even)
+    static_assert(T >= 15 && T <= 32, "the 64-lane tap table of init() holds j = -16 .. 47");
     v4i p1[2], p2[2], p3[2];
 
+    // Every entry of the operand is ONE table value: lane (m, g), K-step s, entry 8 g + 2 q + u carries the tap j = (m - 8 g) + (T - 32 s - 2 q - u),
+    // a per-lane base plus a compile-time offset.  The table (the tap's two limbs as 16 bits, zero outside 0 <= j < T) is built once, one
+    // value per lane -- lane l holds j = l - 16, which covers every j any entry can ask for once j < -16 is clamped (those are zero) --
+    // and the 16 entries are ds_bpermute reads of it (a select chain per ENTRY was 1250 instructions of prologue, half a sub-chunk's work,
+    // in every workgroup of the short launches).
     __device__ __forceinline__ void init(int lane)
     {
         const int m = lane & 15, g = lane >> 4;
+        const int jt = lane - 16;
+        int h = 0;
+#pragma unroll
+        for (int t = 0; t < T; t++) if (t == jt) h = hb_tap<ORDER>(t);
+        auto limbs = [](int hv) -> int {                                        // (hh & 255) << 8 | (hl & 255), h = 256 hh + hl, hl in [-128, 127]
+            const int l = ((hv & 255) ^ 128) - 128;
+            const int hh = (hv - l) >> 8;
+            return (int)((((uint32_t)hh & 255u) << 8) | ((uint32_t)l & 255u));
+        };
+        const int tab = limbs(h), tabn = ALT ? limbs(-h) : tab;                  // ALT: entries with an even window index carry -h
+        const int base = 4 * (m - 8 * g + 16);                                  // byte address of the lane that holds j = m - 8 g
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             uint32_t d1[4], d2[4], d3[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                uint32_t a1 = 0, a2 = 0, a3 = 0;
+                uint32_t x[2];
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
-                    const int w = 32 * s + 8 * g + 2 * q + u;
-                    const int j = m + T - w;
-                    int h = 0;
-#pragma unroll
-                    for (int t = 0; t < T; t++) if (t == j) h = hb_tap<ORDER>(t);
-                    if (ALT && (w & 1) == 0) h = -h;
-                    const int l = ((h & 255) ^ 128) - 128;                      // hl in [-128, 127]
-                    const int hh = (h - l) >> 8;
-                    const uint32_t lo = (uint32_t)l & 255u, hi = (uint32_t)hh & 255u;
-                    a3 |= lo << (16 * u);
-                    a2 |= (hi | (lo << 8)) << (16 * u);
-                    a1 |= (hi << 8) << (16 * u);
+                    int a = base + 4 * (T - 32 * s - 2 * q - u);
+                    if (s == 1) a = a < 0 ? 0 : a;                              // j < -16: lane 0 holds a zero
+                    x[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(a, u == 0 ? tabn : tab);   // window index parity = parity of u
                 }
-                d1[q] = a1; d2[q] = a2; d3[q] = a3;
+                const uint32_t y = x[0] | (x[1] << 16);
+                d3[q] = y & 0x00ff00ffu;                                        // hl
+                d2[q] = __builtin_amdgcn_perm(y, y, 0x02030001u);               // hh | hl << 8
+                d1[q] = y & 0xff00ff00u;                                        // hh << 8
             }
             p1[s] = v4i{ (int)d1[0], (int)d1[1], (int)d1[2], (int)d1[3] };
             p2[s] = v4i{ (int)d2[0], (int)d2[1], (int)d2[2], (int)d2[3] };
