@@ -188,9 +188,13 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
     auto fetch = [&](long chunk) {
         const long c0 = chunk * C;
         if (c0 >= sp.t_old && c0 + C <= sp.t_new) {               // the whole chunk lies in this feed (wave-uniform): no per-lane tests
-            const uint4* src = reinterpret_cast<const uint4*>(sp.in + (c0 - sp.t_old));
+            // GLOBAL loads, not flat ones (the pointer comes out of a table, so the compiler cannot tell): a flat load also counts on
+            // lgkmcnt, and then the first LDS wait of the level loop waits for the whole prefetch
+            typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+            typedef const u4v __attribute__((address_space(1))) gq4;
+            gq4* src = (gq4*)reinterpret_cast<const u4v*>(sp.in + (c0 - sp.t_old));
 #pragma unroll
-            for (int j = 0; j < LPT; j++) pre[j] = src[j * NT + tid];
+            for (int j = 0; j < LPT; j++) { const u4v v = src[j * NT + tid]; pre[j] = make_uint4(v[0], v[1], v[2], v[3]); }
             return;
         }
 #pragma unroll
@@ -208,6 +212,9 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                 pre[j] = make_uint4(v[0], v[1], v[2], v[3]);
             }
         }
+        // (boundary chunks only) nothing of this path stays in flight: loads pending in its scratch registers make the compiler drain
+        // vmcnt in front of the level loop on EVERY path, which exposes the whole prefetch of the fast path above
+        __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0) only
     };
     fetch(first - st.warm);
     __syncthreads();
