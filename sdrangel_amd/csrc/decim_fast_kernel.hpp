@@ -588,15 +588,20 @@ void decim_fast_kernel(const DecimJobs jobs, int spw, int post, int in_shift)
                     const uint32_t keepv = tc ? p23 : p01, snd = tc ? p01 : p23;
                     const uint32_t rcv = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd, 0xB1, 0xf, 0xf, true);
                     const uint32_t rep = tc ? rcv : keepv, imp = tc ? keepv : rcv;
+                    // the prefetch of the next raw sub-chunk goes out HERE: its 16 registers are free while the tile above runs -- and BEFORE the
+                    // output stores: the compiler drains vmcnt in front of the prefetch (its registers may still be pending on the drain path),
+                    // which behind the stores was a wait for their acknowledgement in every iteration
+                    const uint32_t w0 = __builtin_amdgcn_perm(imp, rep, 0x05040100u), w1 = __builtin_amdgcn_perm(imp, rep, 0x07060302u);
+                    cbar();
+                    if (it + 1 < last) fetch(it + 1);
+                    cbar();
                     if (on && t_stage == L && subS >= first) {
                         const long base = subS * (S >> L) + 16 * t_blk + 4 * g4 + 2 * tc;
-                        if (base < n_out)     out[base]     = __builtin_amdgcn_perm(imp, rep, 0x05040100u);
-                        if (base + 1 < n_out) out[base + 1] = __builtin_amdgcn_perm(imp, rep, 0x07060302u);
+                        if (base < n_out)     out[base]     = w0;
+                        if (base + 1 < n_out) out[base + 1] = w1;
                     }
                 }
                 cbar();
-                // the prefetch of the next raw sub-chunk goes out HERE: its 16 registers are free while the tile above runs
-                if (it + 1 < last) fetch(it + 1);
             }
             static_for<0, (MXT ? 3 : L)>([&](auto ic) {
                 constexpr int s = (MXT ? 3 : L) - decltype(ic)::value;

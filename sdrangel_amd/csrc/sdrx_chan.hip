@@ -417,7 +417,11 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
             if (any) st.lds_dwords = trash + 64;
         }
         if (st.lds_dwords > 0xffff) { set_error("channel tree does not fit the 16-bit LDS offsets of the array table"); return SDRX_EINVAL; }
-        for (int l = 0; l < levels; l++) st.lv[l].in_len = arm_len(l);
+        for (int l = 0; l < levels; l++) {
+            st.lv[l].in_len = arm_len(l);
+            st.lv[l].prev_arr_base = l == 0 ? 0 : st.lv[l - 1].arr_base;
+            st.lv[l].prev_arr_cnt = l == 0 ? st.root_arr_cnt : st.lv[l - 1].arr_cnt;
+        }
         g->max_lds_dw = std::max(g->max_lds_dw, st.lds_dwords);
         g->streams[si].subtree = (int)g->subtrees.size();
         g->subtrees.push_back(st);
@@ -617,6 +621,7 @@ static int feed_group(sdrx_chan_bank* b, Group* g, const uint32_t* d_in, int64_t
         const int s0 = ps.front(), cnt = (int)ps.size();
         size_t lds_bytes = 0;                              // per pass: a deep pass must not cost the shallow ones their occupancy
         for (int si : ps) lds_bytes = std::max(lds_bytes, (size_t)g->subtrees[(size_t)g->streams[(size_t)si].subtree].lds_dwords * 4);
+        { const char* e = getenv("SDRX_CHAN_LDS_PAD_KB"); if (e) lds_bytes += (size_t)atoi(e) * 1024; }   // occupancy experiments only
         if (g->mfma)
             hipLaunchKernelGGL(tree_kernel<true>, dim3((unsigned)max_segs, (unsigned)cnt), dim3(TK_THREADS), lds_bytes, b->stream,
                                g->d_subtrees, g->d_nodes, g->d_arrays, d_streams + s0, d_sinks, g->d_mjobs);

@@ -62,7 +62,11 @@ struct TkLevel {
     int mfma;                                    // 1: the level runs on the matrix cores (hb_mfma.hpp): nout >= 256, whole jobs per entry
     int mjob_base, n_mjobs;                      // its jobs in the group's TkMJob table (a job = 16 blocks of 16 outputs of one entry, I and Q = two MFMA tiles)
     uint32_t xm;                                 // XORed into the odd-arm dwords this level PRODUCES: HBM_BIAS2 if the next level is an MFMA level
+    int prev_arr_base, prev_arr_cnt;             // the arrays this level READS = its parents' (level 1: the root arms): copied here so that the
+                                                 // kernel gets a level with ONE wide scalar load (each dependent one is a ~200-cycle round trip)
+    int pad[2];
 };
+static_assert(sizeof(TkLevel) == 64, "one s_load_dwordx16 per level");
 
 // One matrix-core job, everything resolved by the planner to LDS BYTE addresses of the job's first element (the lane adds its
 // share): wave-uniform, fetched with three wide scalar loads.  o[0] / o[1]: a centre stage uses o[0]; a lower/upper pair has the
@@ -183,6 +187,13 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
     if constexpr (MX) taps.init(lane);
     const uint32_t root_xm = MX ? st.root_xm : 0u;
     const int dbg = st.dbg;
+    // loop bounds and table offsets the level loop needs at every turn: pinned in registers (opaque to the compiler, which otherwise
+    // re-loads them from the descriptor inside the loops -- a scalar-cache round trip in front of every level and every history walk)
+    int n_levels = st.n_levels, arr_tab = st.arr_tab;
+    asm volatile("" : "+s"(n_levels), "+s"(arr_tab));
+    // the same for the root fill at the top of every chunk (eight dependent scalar loads before the first LDS write otherwise)
+    int rE_I = st.rootE_I, rE_Q = st.rootE_Q, rO_I = st.rootO_I, rO_Q = st.rootO_Q, rA_I = st.rootA_I, rA_Q = st.rootA_Q, root_cnt16 = st.root_arr_cnt * 16;
+    asm volatile("" : "+s"(rE_I), "+s"(rE_Q), "+s"(rO_I), "+s"(rO_Q), "+s"(rA_I), "+s"(rA_Q), "+s"(root_cnt16));
 
     uint4 pre[LPT];
     auto fetch = [&](long chunk) {
@@ -228,41 +239,47 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
             const uint4 v = pre[j];
             const uint32_t oI = __builtin_amdgcn_perm(v.w, v.y, 0x05040100u);
             const uint32_t oQ = __builtin_amdgcn_perm(v.w, v.y, 0x07060302u);
-            lds[st.rootE_I + q] = __builtin_amdgcn_perm(v.z, v.x, 0x05040100u);
-            lds[st.rootE_Q + q] = __builtin_amdgcn_perm(v.z, v.x, 0x07060302u);
-            if (st.rootO_I >= 0) { lds[st.rootO_I + q] = oI ^ root_xm; lds[st.rootO_Q + q] = oQ ^ root_xm; }
-            if (st.rootA_I >= 0) {
+            lds[rE_I + q] = __builtin_amdgcn_perm(v.z, v.x, 0x05040100u);
+            lds[rE_Q + q] = __builtin_amdgcn_perm(v.z, v.x, 0x07060302u);
+            if (rO_I >= 0) { lds[rO_I + q] = oI ^ root_xm; lds[rO_Q + q] = oQ ^ root_xm; }
+            if (rA_I >= 0) {
                 // odd-arm index m even (low half) -> wrap-negated, m odd -> as is
                 typedef unsigned short us2r __attribute__((ext_vector_type(2)));
                 const us2r sg = { 0xffffu, 1u };                                   // one packed multiply by (-1, +1): the low half wraps
-                lds[st.rootA_I + q] = __builtin_bit_cast(uint32_t, (us2r)(__builtin_bit_cast(us2r, oI) * sg)) ^ root_xm;
-                lds[st.rootA_Q + q] = __builtin_bit_cast(uint32_t, (us2r)(__builtin_bit_cast(us2r, oQ) * sg)) ^ root_xm;
+                lds[rA_I + q] = __builtin_bit_cast(uint32_t, (us2r)(__builtin_bit_cast(us2r, oI) * sg)) ^ root_xm;
+                lds[rA_Q + q] = __builtin_bit_cast(uint32_t, (us2r)(__builtin_bit_cast(us2r, oQ) * sg)) ^ root_xm;
             }
         }
-        for (int i = tid; i < st.root_arr_cnt * 16; i += NT) {                 // history in front of the root windows
-            const uint32_t a = lds[st.arr_tab + (i >> 4)];
+        for (int i = tid; i < root_cnt16; i += NT) {                           // history in front of the root windows
+            const uint32_t a = lds[arr_tab + (i >> 4)];
             lds[(a & 0xffffu) + (i & 15)] = lds[(a >> 16) + (i & 15)];
         }
         if (chunk < last) fetch(chunk + 1);
         __syncthreads();
 
         const bool live = chunk >= first;
-        for (int l = 0; l < st.n_levels; l++) {
-            const TkLevel lv = st.lv[l];
+        for (int l = 0; l < n_levels; l++) {
+            // the level record: one s_load_dwordx16 (field by field the compiler fetches it in three dependent pieces)
+            typedef int s16i __attribute__((ext_vector_type(16)));
+            const s16i rec = *(const s16i __attribute__((address_space(4)))*)reinterpret_cast<const int*>(&st.lv[l]);
+            TkLevel lv;
+            lv.node_base = rec[0]; lv.n_nodes = rec[1]; lv.jobs_log2 = rec[2]; lv.nout = rec[3]; lv.arr_base = rec[4]; lv.arr_cnt = rec[5];
+            lv.r_log2 = rec[6]; lv.in_len = rec[7]; lv.mfma = rec[8]; lv.mjob_base = rec[9]; lv.n_mjobs = rec[10]; lv.xm = (uint32_t)rec[11];
+            lv.prev_arr_base = rec[12]; lv.prev_arr_cnt = rec[13];
             const int njobs = lv.n_nodes << lv.jobs_log2;
             {   // ONE pass over the per-array table, before the jobs: (1) history of the arrays this level PRODUCES goes in
                 // front of their windows, (2) the arrays this level READS are complete and only read from here on, so their
                 // last 16 dwords are kept for the next chunk now (this used to be a second dependent LDS round trip behind
                 // the jobs of every level).
-                const int sb = l == 0 ? 0 : st.lv[l - 1].arr_base, sc = l == 0 ? st.root_arr_cnt : st.lv[l - 1].arr_cnt;
+                const int sb = lv.prev_arr_base, sc = lv.prev_arr_cnt;
                 const int n_restore = lv.arr_cnt * 16, n_all = (dbg & 2) ? 0 : n_restore + sc * 16;
                 for (int i = tid; i < n_all; i += NT) {
                     if (i < n_restore) {
-                        const uint32_t a = lds[st.arr_tab + lv.arr_base + (i >> 4)];
+                        const uint32_t a = lds[arr_tab + lv.arr_base + (i >> 4)];
                         lds[(a & 0xffffu) + (i & 15)] = lds[(a >> 16) + (i & 15)];
                     } else {
                         const int k = i - n_restore;
-                        const uint32_t a = lds[st.arr_tab + sb + (k >> 4)];
+                        const uint32_t a = lds[arr_tab + sb + (k >> 4)];
                         lds[(a >> 16) + (k & 15)] = lds[(a & 0xffffu) + lv.in_len - 16 + (k & 15)];
                     }
                 }
