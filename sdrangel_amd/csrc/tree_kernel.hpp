@@ -99,7 +99,8 @@ struct TkSubtree {
     int rootE_I, rootE_Q, rootO_I, rootO_Q, rootA_I, rootA_Q;   // root arms (-1: none)
     uint32_t root_xm;           // XORed into the root odd arms (HBM_BIAS2 if level 1 is an MFMA level)
     int dbg;                    // timing experiments only (SDRX_CHAN_DBG, results are WRONG when set): 1 skip MFMA jobs, 2 skip the
-                                // history walks, 4 skip the root fill, 16 skip the MFMA epilogues
+                                // history walks, 4 skip the root fill (a bit 16, skip the MFMA epilogues, gave DESIGN 4.3a its split and was
+                                // removed: its branch sat between the MFMAs and the epilogues of every pair)
     TkLevel lv[TK_MAX_LEVELS];
 };
 
@@ -186,7 +187,12 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     if constexpr (MX) taps.init(lane);
     const uint32_t root_xm = MX ? st.root_xm : 0u;
-    const int dbg = st.dbg;
+    // timing by elimination (TkSubtree::dbg) is compiled in only by `make EXTRA=-DSDRX_TK_DBG=1` (tools/dbgsweep_chan.sh does that on the GPU
+    // box): even never-taken, its branches split the basic blocks of the hot loops (the one between the MFMAs and the epilogues cost 5 %)
+#ifndef SDRX_TK_DBG
+#define SDRX_TK_DBG 0
+#endif
+    const int dbg = SDRX_TK_DBG ? st.dbg : 0;
     // loop bounds and table offsets the level loop needs at every turn: pinned in registers (opaque to the compiler, which otherwise
     // re-loads them from the descriptor inside the loops -- a scalar-cache round trip in front of every level and every history walk)
     int n_levels = st.n_levels, arr_tab = st.arr_tab;
@@ -396,7 +402,6 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                     __builtin_amdgcn_sched_barrier(0);                             // every LDS read of the pair is in flight before the first MFMA
                     const v4i SI0 = taps.tile(r0.bI0, r0.bI1, bias), SQ0 = taps.tile(r0.bQ0, r0.bQ1, bias);
                     const v4i SI1 = taps.tile(r1.bI0, r1.bI1, bias), SQ1 = taps.tile(r1.bQ0, r1.bQ1, bias);
-                    if ((dbg & 16) && (SI0[0] ^ SQ0[1] ^ SI1[2] ^ SQ1[3]) != 0x12345678) continue;
                     finish(r0, SI0, SQ0, h0, a0, b0);
                     finish(r1, SI1, SQ1, h1, a1, b1);
                 }
@@ -406,7 +411,7 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                     JobIn r0;
                     load(h0, r0);
                     const v4i SI0 = taps.tile(r0.bI0, r0.bI1, bias), SQ0 = taps.tile(r0.bQ0, r0.bQ1, bias);
-                    if (!((dbg & 16) && (SI0[0] ^ SQ0[1]) != 0x12345678)) finish(r0, SI0, SQ0, h0, a0, b0);
+                    finish(r0, SI0, SQ0, h0, a0, b0);
                 }
                 __syncthreads();
                 continue;
