@@ -377,10 +377,10 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
             const TkArray& a = g->arrays[(size_t)(st.array_base + i)];
             if (a.bias && (a.off & 3)) { set_error("internal: MFMA window not 16-byte aligned"); return SDRX_EINVAL; }
         }
+        st.store_base = store_base;
         st.node_tab = store_base + 16 * st.n_arrays;
-        st.arr_tab = st.node_tab + rel_nodes * TK_NODE_DW;
         st.n_sinks = (int)g->sinks.size() - st.sink_base;
-        st.sink_tab = (st.arr_tab + st.n_arrays + 1) & ~1;                  // 8-byte aligned: read as uint2
+        st.sink_tab = (st.node_tab + rel_nodes * TK_NODE_DW + 1) & ~1;      // 8-byte aligned: read as uint2
         st.lds_dwords = st.sink_tab + st.n_sinks * TK_SINK_DW;
         {   // matrix-core jobs: LDS byte addresses of every array a job touches, 256 tb outputs into the chunk; 64 dwords of
             // scratch take the stores to arm arrays a child does not have
@@ -419,9 +419,26 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
         if (st.lds_dwords > 0xffff) { set_error("channel tree does not fit the 16-bit LDS offsets of the array table"); return SDRX_EINVAL; }
         for (int l = 0; l < levels; l++) {
             st.lv[l].in_len = arm_len(l);
-            st.lv[l].prev_arr_base = l == 0 ? 0 : st.lv[l - 1].arr_base;
-            st.lv[l].prev_arr_cnt = l == 0 ? st.root_arr_cnt : st.lv[l - 1].arr_cnt;
+            // the walk's address arithmetic (tree_kernel.hpp): a level's arrays are contiguous, of one length, slots in array order
+            const int pb = l == 0 ? 0 : st.lv[l - 1].arr_base, pc = l == 0 ? st.root_arr_cnt : st.lv[l - 1].arr_cnt;
+            st.lv[l].prev_arr_cnt = pc;
+            st.lv[l].prev_off = pc ? g->arrays[(size_t)(st.array_base + pb)].off : 0;
+            st.lv[l].arr_off = st.lv[l].arr_cnt ? g->arrays[(size_t)(st.array_base + st.lv[l].arr_base)].off : 0;
+            st.lv[l].arr_len = st.lv[l].arr_cnt ? g->arrays[(size_t)(st.array_base + st.lv[l].arr_base)].len : 0;
+            if (pb + pc != st.lv[l].arr_base) { set_error("internal: level arrays not in order"); return SDRX_EINVAL; }
+            for (int k = 0; k < st.lv[l].arr_cnt; k++) {
+                const TkArray& a = g->arrays[(size_t)(st.array_base + st.lv[l].arr_base + k)];
+                if (a.off != st.lv[l].arr_off + k * st.lv[l].arr_len || a.len != st.lv[l].arr_len || a.store != st.store_base + 16 * (st.lv[l].arr_base + k)) {
+                    set_error("internal: level arrays not contiguous"); return SDRX_EINVAL;
+                }
+            }
+            for (int k = 0; k < pc; k++) {
+                const TkArray& a = g->arrays[(size_t)(st.array_base + pb + k)];
+                if (a.off != st.lv[l].prev_off + k * st.lv[l].in_len || a.len != st.lv[l].in_len) { set_error("internal: parent arrays not contiguous"); return SDRX_EINVAL; }
+            }
         }
+        st.root_off = st.root_arr_cnt ? g->arrays[(size_t)st.array_base].off : 0;
+        st.root_len = st.root_arr_cnt ? g->arrays[(size_t)st.array_base].len : 0;
         g->max_lds_dw = std::max(g->max_lds_dw, st.lds_dwords);
         g->streams[si].subtree = (int)g->subtrees.size();
         g->subtrees.push_back(st);

@@ -62,9 +62,12 @@ struct TkLevel {
     int mfma;                                    // 1: the level runs on the matrix cores (hb_mfma.hpp): nout >= 256, whole jobs per entry
     int mjob_base, n_mjobs;                      // its jobs in the group's TkMJob table (a job = 16 blocks of 16 outputs of one entry, I and Q = two MFMA tiles)
     uint32_t xm;                                 // XORed into the odd-arm dwords this level PRODUCES: HBM_BIAS2 if the next level is an MFMA level
-    int prev_arr_base, prev_arr_cnt;             // the arrays this level READS = its parents' (level 1: the root arms): copied here so that the
-                                                 // kernel gets a level with ONE wide scalar load (each dependent one is a ~200-cycle round trip)
-    int pad[2];
+    // The arrays of one level are allocated back to back with one length (sdrx_chan.hip), and so are their history slots (16 dwords each,
+    // in array order): the history walk computes its addresses from these five numbers instead of reading a per-array table from LDS
+    // (a dependent LDS round trip in front of every copy).  Everything a level needs sits in this one 64-byte record = one scalar load.
+    int prev_off, prev_arr_cnt;                  // the arrays this level READS (its parents' arms; level 1: the root arms): first window, count;
+                                                 // their length is in_len, their slots end where this level's begin
+    int arr_off, arr_len;                        // the arrays this level PRODUCES: first window (LDS dword offset), length of each
 };
 static_assert(sizeof(TkLevel) == 64, "one s_load_dwordx16 per level");
 
@@ -95,7 +98,8 @@ struct TkSubtree {
     int sink_base, n_sinks;     // this subtree's sinks are one contiguous run of the group's sink table
     int sink_tab;               // LDS dword offset of the copy of that run (TK_SINK_DW dwords each)
     int node_tab;               // LDS dword offset of the node table copy
-    int arr_tab;                // LDS dword offset of the array table copy: off | store << 16, one dword per array
+    int store_base;             // LDS dword offset of the history slots: 16 dwords per array, in array order (root arms first)
+    int root_off, root_len;     // the root arms: first window, length of each
     int rootE_I, rootE_Q, rootO_I, rootO_Q, rootA_I, rootA_Q;   // root arms (-1: none)
     uint32_t root_xm;           // XORed into the root odd arms (HBM_BIAS2 if level 1 is an MFMA level)
     int dbg;                    // timing experiments only (SDRX_CHAN_DBG, results are WRONG when set): 1 skip MFMA jobs, 2 skip the
@@ -152,8 +156,6 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
     const long first = sp.c_first + (long)blockIdx.x * sp.cps;
     if (first > sp.c_last) return;
     long last = first + sp.cps - 1; if (last > sp.c_last) last = sp.c_last;
-    // The per-array table the level loop walks three times per level and chunk is copied into LDS once per workgroup, one
-    // dword per array (window offset | history slot << 16): read from global memory each walk is a dependent ~1 us round trip.
     // (The subtree descriptor stays in global/constant memory: the compiler keeps its fields in SGPRs; an LDS copy of it
     // turned every `st.` access into an LDS load and tripled the kernel time.)
     const TkSubtree& st = subtrees[sp.subtree];
@@ -161,13 +163,9 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
 
     for (int i = tid; i < st.lds_dwords; i += NT) lds[i] = 0;
     __syncthreads();
-    {   // node table and array table -> LDS
+    {   // node table -> LDS
         const uint32_t* src = reinterpret_cast<const uint32_t*>(nodes + st.node_base);
         for (int i = tid; i < st.n_nodes * TK_NODE_DW; i += NT) lds[st.node_tab + i] = src[i];
-        for (int i = tid; i < st.n_arrays; i += NT) {
-            const TkArray a = arrays[st.array_base + i];
-            lds[st.arr_tab + i] = (uint32_t)a.off | ((uint32_t)a.store << 16);
-        }
         // this feed's sink descriptors (pointers, ranges): read by every job of the sink levels -- from LDS, not as a
         // dependent global load in front of the stores
         const uint32_t* sk = reinterpret_cast<const uint32_t*>(sinks + st.sink_base);
@@ -195,8 +193,8 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
     const int dbg = SDRX_TK_DBG ? st.dbg : 0;
     // loop bounds and table offsets the level loop needs at every turn: pinned in registers (opaque to the compiler, which otherwise
     // re-loads them from the descriptor inside the loops -- a scalar-cache round trip in front of every level and every history walk)
-    int n_levels = st.n_levels, arr_tab = st.arr_tab;
-    asm volatile("" : "+s"(n_levels), "+s"(arr_tab));
+    int n_levels = st.n_levels, store_base = st.store_base, root_off = st.root_off, root_len = st.root_len;
+    asm volatile("" : "+s"(n_levels), "+s"(store_base), "+s"(root_off), "+s"(root_len));
     // the same for the root fill at the top of every chunk (eight dependent scalar loads before the first LDS write otherwise)
     int rE_I = st.rootE_I, rE_Q = st.rootE_Q, rO_I = st.rootO_I, rO_Q = st.rootO_Q, rA_I = st.rootA_I, rA_Q = st.rootA_Q, root_cnt16 = st.root_arr_cnt * 16;
     asm volatile("" : "+s"(rE_I), "+s"(rE_Q), "+s"(rO_I), "+s"(rO_Q), "+s"(rA_I), "+s"(rA_Q), "+s"(root_cnt16));
@@ -256,10 +254,8 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                 lds[rA_Q + q] = __builtin_bit_cast(uint32_t, (us2r)(__builtin_bit_cast(us2r, oQ) * sg)) ^ root_xm;
             }
         }
-        for (int i = tid; i < root_cnt16; i += NT) {                           // history in front of the root windows
-            const uint32_t a = lds[arr_tab + (i >> 4)];
-            lds[(a & 0xffffu) + (i & 15)] = lds[(a >> 16) + (i & 15)];
-        }
+        for (int i = tid; i < root_cnt16; i += NT)                             // history in front of the root windows
+            lds[root_off + (i >> 4) * root_len + (i & 15)] = lds[store_base + i];
         if (chunk < last) fetch(chunk + 1);
         __syncthreads();
 
@@ -271,23 +267,19 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
             TkLevel lv;
             lv.node_base = rec[0]; lv.n_nodes = rec[1]; lv.jobs_log2 = rec[2]; lv.nout = rec[3]; lv.arr_base = rec[4]; lv.arr_cnt = rec[5];
             lv.r_log2 = rec[6]; lv.in_len = rec[7]; lv.mfma = rec[8]; lv.mjob_base = rec[9]; lv.n_mjobs = rec[10]; lv.xm = (uint32_t)rec[11];
-            lv.prev_arr_base = rec[12]; lv.prev_arr_cnt = rec[13];
+            lv.prev_off = rec[12]; lv.prev_arr_cnt = rec[13]; lv.arr_off = rec[14]; lv.arr_len = rec[15];
             const int njobs = lv.n_nodes << lv.jobs_log2;
             {   // ONE pass over the per-array table, before the jobs: (1) history of the arrays this level PRODUCES goes in
                 // front of their windows, (2) the arrays this level READS are complete and only read from here on, so their
                 // last 16 dwords are kept for the next chunk now (this used to be a second dependent LDS round trip behind
                 // the jobs of every level).
-                const int sb = lv.prev_arr_base, sc = lv.prev_arr_cnt;
-                const int n_restore = lv.arr_cnt * 16, n_all = (dbg & 2) ? 0 : n_restore + sc * 16;
+                const int n_restore = lv.arr_cnt * 16, n_all = (dbg & 2) ? 0 : n_restore + lv.prev_arr_cnt * 16;
+                const int slot0 = store_base + 16 * lv.arr_base;                  // this level's slots; its parents' end right there
                 for (int i = tid; i < n_all; i += NT) {
-                    if (i < n_restore) {
-                        const uint32_t a = lds[arr_tab + lv.arr_base + (i >> 4)];
-                        lds[(a & 0xffffu) + (i & 15)] = lds[(a >> 16) + (i & 15)];
-                    } else {
-                        const int k = i - n_restore;
-                        const uint32_t a = lds[arr_tab + sb + (k >> 4)];
-                        lds[(a >> 16) + (k & 15)] = lds[(a & 0xffffu) + lv.in_len - 16 + (k & 15)];
-                    }
+                    const int k = i - n_restore;                                  // i < n_restore: slot -> window head; else: window tail -> slot
+                    const int src = k < 0 ? slot0 + i : lv.prev_off + (k >> 4) * lv.in_len + lv.in_len - 16 + (k & 15);
+                    const int dst = k < 0 ? lv.arr_off + (i >> 4) * lv.arr_len + (i & 15) : slot0 - lv.prev_arr_cnt * 16 + k;
+                    lds[dst] = lds[src];
                 }
             }
             if (MX && lv.mfma) {
@@ -398,10 +390,14 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                     cs8* d1 = (cs8*)reinterpret_cast<const int*>(mjobs + lv.mjob_base + tt + 1);
                     const s8i h0 = d0[0], a0 = d0[1], b0 = d0[2], h1 = d1[0], a1 = d1[1], b1 = d1[2];
                     JobIn r0, r1;
+                    __builtin_amdgcn_s_setprio(2);
                     load(h0, r0); load(h1, r1);
                     __builtin_amdgcn_sched_barrier(0);                             // every LDS read of the pair is in flight before the first MFMA
                     const v4i SI0 = taps.tile(r0.bI0, r0.bI1, bias), SQ0 = taps.tile(r0.bQ0, r0.bQ1, bias);
                     const v4i SI1 = taps.tile(r1.bI0, r1.bI1, bias), SQ1 = taps.tile(r1.bQ0, r1.bQ1, bias);
+                    // (the wave asks for issue priority while it puts its operand loads and MFMAs out: the matrix pipe then works under the
+                    // other waves' epilogues -- 1.3 % at 1 Gi samples, A/B on one box with tools/ab_libs.sh)
+                    __builtin_amdgcn_s_setprio(0);
                     finish(r0, SI0, SQ0, h0, a0, b0);
                     finish(r1, SI1, SQ1, h1, a1, b1);
                 }
