@@ -42,6 +42,14 @@ def _share_hip_runtime_with_torch() -> None:
         C.CDLL(p, mode=C.RTLD_GLOBAL)
 
 
+def _del(self):
+    """Finaliser shared by the handle classes: close(), quietly -- at interpreter shutdown the module's globals may already be gone."""
+    try:
+        self.close()
+    except Exception:
+        pass
+
+
 def lib() -> C.CDLL:
     """Load libsdrx.so (built in-tree by `make -C sdrangel_amd/csrc` / __graft_entry__.build())."""
     global _lib
@@ -241,7 +249,7 @@ class Decimators:
             lib().sdrx_decim_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    __del__ = _del
 
     def reset(self):
         _check(lib().sdrx_decim_reset(self._h), "sdrx_decim_reset")
@@ -352,7 +360,7 @@ class DecimStages:
             lib().sdrx_decim_stages_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    __del__ = _del
 
 
 class DecimatorsObject:
@@ -414,7 +422,7 @@ class Fanout:
             lib().sdrx_fanout_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    __del__ = _del
 
     def send(self, d_src: int, n_bytes: int, producer_stream: int | None = None):
         _check(lib().sdrx_fanout_send(self._h, d_src, n_bytes, producer_stream), "sdrx_fanout_send")
@@ -438,7 +446,7 @@ class FloatDecimStages:
             lib().sdrx_fdecim_stages_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    __del__ = _del
 
 
 class FloatDecimatorsObject:
@@ -486,7 +494,7 @@ class FloatDecimators:
             lib().sdrx_fdecim_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    __del__ = _del
 
     def reset(self):
         _check(lib().sdrx_fdecim_reset(self._h), "sdrx_fdecim_reset")
@@ -536,7 +544,7 @@ class DcCorrection:
             lib().sdrx_dccorr_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    __del__ = _del
 
     def reset(self):
         _check(lib().sdrx_dccorr_reset(self._h), "sdrx_dccorr_reset")
@@ -584,7 +592,7 @@ class ChannelizerBank:
             lib().sdrx_chan_bank_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    __del__ = _del
 
     def info(self, ch: int):
         n, r, f = C.c_int32(), C.c_int32(), C.c_int32()
@@ -678,7 +686,7 @@ class FirBank:
             lib().sdrx_firbank_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    __del__ = _del
 
     def taps(self, ch: int) -> np.ndarray:
         t = np.zeros(4096, np.float32)
@@ -737,7 +745,7 @@ class BackendBank:
             lib().sdrx_backend_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    __del__ = _del
 
     def feed(self, per_channel_iq):
         bufs = [_i16(x) for x in per_channel_iq]
@@ -795,7 +803,7 @@ class AudioTail:
             lib().sdrx_audiotail_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    __del__ = _del
 
     def reset(self):
         _check(lib().sdrx_audiotail_reset(self._h), "sdrx_audiotail_reset")
@@ -833,7 +841,7 @@ class IirBank:
             lib().sdrx_iir_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    __del__ = _del
 
     def reset(self):
         _check(lib().sdrx_iir_reset(self._h), "sdrx_iir_reset")
@@ -862,7 +870,7 @@ class Decimators24:
             lib().sdrx_decim24_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    __del__ = _del
 
     def reset(self):
         _check(lib().sdrx_decim24_reset(self._h), "sdrx_decim24_reset")
@@ -899,7 +907,7 @@ class ChannelizerBank24:
             lib().sdrx_chan24_bank_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    __del__ = _del
 
     def reset(self):
         _check(lib().sdrx_chan24_bank_reset(self._h), "sdrx_chan24_bank_reset")
@@ -948,7 +956,7 @@ class IqImbalance:
             lib().sdrx_iqimb_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    __del__ = _del
 
     def reset(self):
         _check(lib().sdrx_iqimb_reset(self._h), "sdrx_iqimb_reset")
@@ -974,7 +982,7 @@ class SampleSinkFifo:
             lib().sdrx_fifo_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    __del__ = _del
 
     def set_size(self, size: int):
         _check(lib().sdrx_fifo_set_size(self._h, size), "sdrx_fifo_set_size")
