@@ -269,7 +269,7 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
             lv.r_log2 = rec[6]; lv.in_len = rec[7]; lv.mfma = rec[8]; lv.mjob_base = rec[9]; lv.n_mjobs = rec[10]; lv.xm = (uint32_t)rec[11];
             lv.prev_off = rec[12]; lv.prev_arr_cnt = rec[13]; lv.arr_off = rec[14]; lv.arr_len = rec[15];
             const int njobs = lv.n_nodes << lv.jobs_log2;
-            {   // ONE pass over the per-array table, before the jobs: (1) history of the arrays this level PRODUCES goes in
+            {   // ONE pass over the level's arrays, before the jobs: (1) history of the arrays this level PRODUCES goes in
                 // front of their windows, (2) the arrays this level READS are complete and only read from here on, so their
                 // last 16 dwords are kept for the next chunk now (this used to be a second dependent LDS round trip behind
                 // the jobs of every level).
