@@ -416,7 +416,7 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
             }
             if (any) st.lds_dwords = trash + 64;
         }
-        if (st.lds_dwords > 159 * 1024 / 4) {                      // tables and the job scratch on top of the arm regions set_error("channel tree does not fit LDS"); return SDRX_EINVAL; }
+        if (st.lds_dwords > 159 * 1024 / 4) { set_error("channel tree does not fit LDS"); return SDRX_EINVAL; }   // tables and the job scratch on top of the arm regions
         for (int l = 0; l < levels; l++) {
             st.lv[l].in_len = arm_len(l);
             // the walk's address arithmetic (tree_kernel.hpp): a level's arrays are contiguous, of one length, slots in array order
