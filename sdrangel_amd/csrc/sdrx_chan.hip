@@ -409,6 +409,18 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
                         };
                         if (nd.mode_a == SDRX_MODE_UPPER) { put(j.o[0], nullptr); put(j.o[1], &nd.a); }
                         else { put(j.o[0], &nd.a); put(j.o[1], nd.b.present ? &nd.b : nullptr); }
+                        // the common inner job -- a lower/upper pair whose two children are inner nodes with ONE kind of odd arm and no sink --
+                        // gets a branch-free epilogue (tree_kernel.hpp): the odd target moves into O_I / O_Q whatever its kind, `kinds` says which
+                        // children want the alternating-sign copy
+                        auto one_odd = [](const TkMOut& m) { return m.sink < 0 && (m.flags == (1 | 2) || m.flags == (1 | 4)); };
+                        // (the same treatment for single-child pairs and centre stages measured SLOWER, 3.22 vs 3.13 ms: three more inlined store groups
+                        // in both the paired and the single job body)
+                        // (nor did sending single-child pairs down this path with the absent child's stores going to the scratch slot: 3.15 vs 3.13)
+                        const int fast = j.mode && one_odd(j.o[0]) && one_odd(j.o[1]) ? 1 : 0;
+                        if (fast) {
+                            j.fast = fast; j.kinds = ((j.o[0].flags & 4) ? 1 : 0) | ((j.o[1].flags & 4) ? 2 : 0);
+                            for (TkMOut* m : { &j.o[0], &j.o[1] }) if (m->flags & 4) { m->O_I = m->A_I; m->O_Q = m->A_Q; }
+                        }
                         g->mjobs.push_back(j);
                     }
                 }
@@ -444,9 +456,13 @@ static int plan_group(sdrx_chan_bank* b, Group* g)
         g->subtrees.push_back(st);
         if ((int)g->passes.size() <= pass) g->passes.resize(pass + 1);
         g->passes[pass].push_back((int)si);
-        if (getenv("SDRX_CHAN_DEBUG"))
-            fprintf(stderr, "sdrx plan: pass %d stream %d (trie node %d, depth %d): %d levels, %d entries, %d arrays, %d LDS dwords (regions %d + %d)\n",
-                    pass, (int)si, root, g->streams[si].depth, levels, rel_nodes, st.n_arrays, st.lds_dwords, reg_size[0], reg_size[1]);
+        if (getenv("SDRX_CHAN_DEBUG")) {
+            int nj = 0, nf = 0;
+            for (int l = 0; l < levels; l++)
+                for (int q = 0; q < st.lv[l].n_mjobs; q++) { nj++; nf += g->mjobs[(size_t)(st.lv[l].mjob_base + q)].fast; }
+            fprintf(stderr, "sdrx plan: pass %d stream %d (trie node %d, depth %d): %d levels, %d entries, %d arrays, %d LDS dwords (regions %d + %d), %d matrix-core jobs per chunk (%d branch-free)\n",
+                    pass, (int)si, root, g->streams[si].depth, levels, rel_nodes, st.n_arrays, st.lds_dwords, reg_size[0], reg_size[1], nj, nf);
+        }
     }
 
     // device: histories + static tables

@@ -81,7 +81,8 @@ struct TkMJob {
     int cI, cQ;                 // dword holding even-arm entry 16 (16 tb) + 20 (centre taps of the job's first block)
     int mode;                   // 0: centre stage, else lower/upper pair
     int out0;                   // first output of the job inside the chunk: 256 tb
-    int pad[2];
+    int fast, kinds;            // fast = 1: a lower/upper pair whose two children are inner nodes with even arms + ONE odd-arm kind (its address in
+                                // O_I / O_Q) and no sink: stores-only epilogue; kinds bit 0 / 1: child 0 / 1 wants the alternating-sign copy
     TkMOut o[2];
     int pad2[8];
 };
@@ -374,6 +375,22 @@ void tree_kernel(const TkSubtree* __restrict__ subtrees, const TkNode* __restric
                     // centre taps e0..e3 = int16 entries 1, 2, 3, 4 of the three dwords read: (e0, e2) and (e1, e3)
                     const uint32_t cI02 = __builtin_amdgcn_perm(r.cI01.y, r.cI01.x, 0x07060302u), cI13 = __builtin_amdgcn_perm(r.cI2, r.cI01.y, 0x05040100u);
                     const uint32_t cQ02 = __builtin_amdgcn_perm(r.cQ01.y, r.cQ01.x, 0x07060302u), cQ13 = __builtin_amdgcn_perm(r.cQ2, r.cQ01.y, 0x05040100u);
+                    if (h[6]) {
+                        // the common inner job (planner: TkMJob::fast): eight stores, no branch -- the generic path below spends a dozen
+                        // scalar branches per job on presence flags and sink lists, each a bubble in a wave that has little else in flight
+                        typedef unsigned short us2f __attribute__((ext_vector_type(2)));
+                        auto alt = [&](uint32_t v, uint32_t m) { return __builtin_bit_cast(uint32_t, (us2f)(__builtin_bit_cast(us2f, v) * __builtin_bit_cast(us2f, m))) ^ xm; };
+                        const uint32_t ma = (h[7] & 1) ? 0x0001ffffu : 0x00010001u, mb = (h[7] & 2) ? 0x0001ffffu : 0x00010001u;   // (-1, +1) or (+1, +1)
+                        auto st4 = [&](const s8i o, uint32_t eI, uint32_t eQ, uint32_t oI, uint32_t oQ, uint32_t m) {
+                            *reinterpret_cast<uint32_t*>(ldsw + o[0] + pl) = eI;
+                            *reinterpret_cast<uint32_t*>(ldsw + o[1] + pl) = eQ;
+                            *reinterpret_cast<uint32_t*>(ldsw + o[2] + pl) = alt(oI, m);
+                            *reinterpret_cast<uint32_t*>(ldsw + o[3] + pl) = alt(oQ, m);
+                        };
+                        st4(oa, padd(sI02, cI02), psub(sQ02, cQ02), psub(sI13, cI13), padd(sQ13, cQ13), ma);
+                        st4(ob, psub(sI02, cI02), padd(sQ02, cQ02), padd(sI13, cI13), psub(sQ13, cQ13), mb);
+                        return;
+                    }
                     const long abs0 = chunk * lv.nout + h[5] + 16 * n16 + 4 * g4;
                     if (h[4] == 0) {
                         emit(padd(sI02, cI02), padd(sI13, cI13), padd(sQ02, cQ02), padd(sQ13, cQ13), oa, abs0);
